@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- sw2d DG right-hand side + LSERK4 stage on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path: ONE fused RHS + LSERK4 stage over the whole mesh.
+Workload (configs[2] of BASELINE.json): synthetic box [-1,1]^2, 1000 x 500 cells = 10^6
+triangles, N=4 (Np=15), H=10 + Gaussian free surface, fp64, state resident in HBM.
+For --gpus N > 1 the SAME mesh is partitioned into N parts (strong scaling); ghost elements
+are exchanged every stage over RCCL (torch.distributed, one process per GPU) while the
+interior elements compute.
+
+Prints one JSON line (rank 0): metric = element-DOF updates/s (Np*K*stages / wall time), plus
+  roofline     algorithmic HBM bytes (2400 B/element/stage at N=4) over the
+               average stage-kernel duration measured with HIP events on the solver's stream
+  cpu_baseline the CPU oracle (port of the reference algorithm) on a bounded sample, rank 0, N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ORDER = 4
+NX, NY = 1000, 500
+G = 9.81
+CFL = 0.65
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def algorithmic_bytes_per_element(order):
+    """RHS + LSERK4 stage, fp64 values / int32 indices: 128*Np + 96*Nfp."""
+    np_, nfp = (order + 1) * (order + 2) // 2, order + 1
+    return 128 * np_ + 96 * nfp
+
+
+def initial_state(x, y):
+    h = 10.0 + np.exp(-10 * x * x - 10 * y * y)
+    z = np.zeros_like(h)
+    return h, z, z.copy()
+
+
+def cpu_baseline(order):
+    """Times the CPU oracle (oracle/oracle_sw2d.c: pass-by-pass port of the reference's
+    computeRHS + LSERK4 update, gcc -O2, single thread like blitzdg) on a bounded sample of the
+    same workload: a 400 x 125-cell box (10^5 triangles) at the same order, 1 warm-up + 3 timed
+    stages. Also reports the same port with OpenMP on all host cores."""
+    import blitzdg_amd.pyblitzdg as dg
+    from oracle import Sw2dOracle
+
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(400, 125)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    ctx = nodes.dgContext()
+    K, Np = ctx.numElements, ctx.numLocalPoints
+    tabs = dict(Dr=ctx.Dr, Ds=ctx.Ds, Lift=ctx.Lift, rx=ctx.rx, sx=ctx.sx, ry=ctx.ry, sy=ctx.sy, nx=ctx.nx,
+                ny=ctx.ny, Fscale=ctx.Fscale, vmapM=ctx.vmapM, vmapP=ctx.vmapP,
+                mapW=np.array(ctx.BCmap[3], dtype=np.int32))
+    h, hu, hv = initial_state(ctx.x, ctx.y)
+    cores = os.cpu_count() or 1
+    out = {}
+    for label, threads, stages in (("single", 1, 3), ("all", cores, 6)):
+        o = Sw2dOracle(g=G, threads=threads, **tabs)
+        dt = 1e-4
+        res = [np.zeros_like(h) for _ in range(3)]
+        q = o.lserk4_stages(h, hu, hv, res, dt, 0, 1)  # warm-up (page faults, caches)
+        t0 = time.perf_counter()
+        o.lserk4_stages(q[0], q[1], q[2], q[3], dt, 1, stages)
+        sec = time.perf_counter() - t0
+        out[label] = Np * K * stages / sec
+    return {"value": out["single"], "unit": "element-DOF updates/s", "cores": 1, "kind": "port",
+            "sample": f"CPU oracle (C port of sw2d-simple computeRHS + LSERK4 stage, gcc -O2, 1 thread), "
+                      f"400x125-cell box = {K} triangles, N={order}, 3 timed stages",
+            "value_all_cores": out["all"], "cores_all": cores,
+            "gbps_algorithmic_single": out["single"] / Np * algorithmic_bytes_per_element(order) / 1e9}
+
+
+def run_single(args):
+    import blitzdg_amd.pyblitzdg as dg
+    from blitzdg_amd import sw2d
+
+    t_setup = time.perf_counter()
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(NX, NY)
+    nodes = dg.TriangleNodesProvisioner(ORDER, mesh)
+    ctx = nodes.dgContext()
+    K, Np = ctx.numElements, ctx.numLocalPoints
+    solver = sw2d.Sw2dSolver(nodes=nodes, g=G, device=0)
+    h, hu, hv = initial_state(ctx.x, ctx.y)
+    solver.setState(h, hu, hv)
+    dt, _ = solver.computeDt(CFL)
+    t_setup = time.perf_counter() - t_setup
+
+    solver.lserk4Stages(dt, args.warmup)
+    solver.synchronize()
+    t0 = time.perf_counter()
+    ms_per_launch = solver.timeLSERK4Stages(dt, args.steps)  # exactly K launches, HIP events on their stream
+    solver.synchronize()
+    wall = time.perf_counter() - t0
+    _, eta_max = solver.computeDt(CFL)  # raises if the run blew up
+
+    bytes_elem = algorithmic_bytes_per_element(ORDER)
+    achieved = bytes_elem * K / (ms_per_launch * 1e-3) / 1e9
+    line = {
+        "metric": "element-DOF updates/sec (sw2d RHS + LSERK4 stage, N=4, 1M tris)",
+        "value": Np * K * args.steps / wall,
+        "unit": "element-DOF updates/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "sw2d RHS + fused LSERK4 stage, synthetic box 1000x500 cells = 1e6 triangles, "
+                               "N=4 (Np=15), natural element order, walls on all sides",
+                   "order": ORDER, "elements": K, "fields": 3, "step": "one fused RHS+LSERK4 stage launch",
+                   "dt": dt, "eta_max_after": eta_max, "setup_seconds": round(t_setup, 2),
+                   "device_bytes": solver.deviceBytes},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "algorithmic_bytes_per_launch": bytes_elem * K, "kernel_ms": ms_per_launch,
+                     "kernel": "sw2d_stage_kernel<4, MODE_LSERK, false>"},
+    }
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(ORDER)
+    print(json.dumps(line), flush=True)
+
+
+def run_distributed(args):
+    import torch
+    import torch.distributed as dist
+
+    from blitzdg_amd.halo import DistributedSw2d
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    try:
+        d = DistributedSw2d.box(NX, NY, ORDER, g=G, device=local_rank)
+        d.set_initial_state(initial_state)
+        dt = d.compute_dt(CFL)
+        for _ in range(args.warmup):
+            d.lserk4_stage(dt)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            d.lserk4_stage(dt)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+        wall = wall.item()
+        d.compute_dt(CFL)  # blow-up check
+        if rank == 0:
+            K, Np = d.global_elements, d.Np
+            bytes_elem = algorithmic_bytes_per_element(ORDER)
+            achieved = bytes_elem * K * args.steps / wall / 1e9
+            line = {
+                "metric": "element-DOF updates/sec (sw2d RHS + LSERK4 stage, N=4, 1M tris)",
+                "value": Np * K * args.steps / wall,
+                "unit": "element-DOF updates/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": wall / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": "sw2d RHS + fused LSERK4 stage, synthetic box 1000x500 cells = 1e6 "
+                                       f"triangles, N=4, partitioned into {world} parts (RCB), ghost-element "
+                                       "halo over RCCL overlapped with interior elements",
+                           "order": ORDER, "elements": K, "fields": 3, "parallelism": f"elem-partition x{world}",
+                           "halo_elements_per_rank": d.halo_counts()},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                             "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
+                             "note": "whole-job wall time incl. halo exchange, not a per-kernel figure"},
+            }
+            print(json.dumps(line), flush=True)
+    finally:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        run_distributed(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

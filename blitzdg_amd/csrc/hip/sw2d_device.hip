@@ -1,0 +1,695 @@
+// sw2d_device.hip -- device-resident sw2d solver behind the C ABI
+// (include/blitzdg_hip.h, group 2). Owns the HBM image of the DG tables and the
+// state, launches the fused stage kernels (sw2d_kernels.hpp) on its own stream.
+//
+// HBM layout (fp64 planes of `ld` = K rounded up to 64 elements per nodal row):
+//   qA, qB      3*Np*ld   state (h, hu, hv), double-buffered across stages
+//   res         3*Np*ld   LSERK4 residual
+//   aux         3*Np*ld   RHS output / RK2 intermediate stage
+//   geo         4*Np*ld   rx, sx, ry, sy
+//   fgeo        9*Nfp*ld  nx, ny, Fscale
+//   vmapP       3*Nfp*ld  int32 gather offsets (wall flag in the sign bit)
+//   ops         Dr|Ds interleaved, Lift, Filter (copied to LDS by every workgroup)
+// Elements may be renumbered internally (BDG_SW2D_REORDER); all I/O is in the
+// caller's numbering.
+#include "../host/capi_internal.hpp"
+#include "blitzdg/LSERK4.hpp"
+#include "sw2d_launch.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <queue>
+#include <string>
+#include <vector>
+
+namespace bdg_dev {
+
+const KernelTable* kernel_table_order1();
+const KernelTable* kernel_table_order2();
+const KernelTable* kernel_table_order3();
+const KernelTable* kernel_table_order4();
+const KernelTable* kernel_table_order5();
+const KernelTable* kernel_table_order6();
+
+const KernelTable* kernel_table(int order) {
+    switch (order) {
+    case 1: return kernel_table_order1();
+    case 2: return kernel_table_order2();
+    case 3: return kernel_table_order3();
+    case 4: return kernel_table_order4();
+    case 5: return kernel_table_order5();
+    case 6: return kernel_table_order6();
+    default: return nullptr;
+    }
+}
+
+// Final reduction of the per-block partials of sw2d_dt_kernel (single block).
+__global__ __launch_bounds__(256) void sw2d_reduce_kernel(const double* __restrict__ part, int nblocks,
+                                                          double* __restrict__ out2) {
+    __shared__ double sA[256], sB[256];
+    __shared__ int sBad;
+    if (threadIdx.x == 0) sBad = 0;
+    __syncthreads();
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x) {
+        const double x = part[2 * i], y = part[2 * i + 1];
+        if (x != x || y != y) sBad = 1;
+        a = fmax(a, x);
+        b = fmax(b, y);
+    }
+    sA[threadIdx.x] = a;
+    sB[threadIdx.x] = b;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (static_cast<int>(threadIdx.x) < s) {
+            sA[threadIdx.x] = fmax(sA[threadIdx.x], sA[threadIdx.x + s]);
+            sB[threadIdx.x] = fmax(sB[threadIdx.x], sB[threadIdx.x + s]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double nan = __builtin_nan("");
+        out2[0] = sBad ? nan : sA[0];
+        out2[1] = sBad ? nan : sB[0];
+    }
+}
+
+// (rows, K) caller-order image <-> padded, optionally renumbered device planes.
+// perm[k_caller] = device slot (NULL = identity). One thread per (row, element).
+template <typename T>
+__global__ void scatter_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int K, long long ld,
+                                    const int* __restrict__ perm) {
+    const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<long long>(rows) * K) return;
+    const long long r = t / K, k = t % K;
+    dst[r * ld + (perm ? perm[k] : k)] = src[t];
+}
+
+template <typename T>
+__global__ void gather_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, int rows, int K, long long ld,
+                                   const int* __restrict__ perm) {
+    const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<long long>(rows) * K) return;
+    const long long r = t / K, k = t % K;
+    dst[t] = src[r * ld + (perm ? perm[k] : k)];
+}
+
+// Halo exchange staging: element-major buffers of 3*Np doubles per element.
+//   pack:   buf[i*rows + r] = q[r*ld + slots[i]]        (owned elements a neighbour rank needs)
+//   unpack: q[r*ld + first + i] = buf[i*rows + r]       (ghost elements, stored after the owned ones)
+__global__ void halo_pack_kernel(const double* __restrict__ q, double* __restrict__ buf, const int* __restrict__ slots,
+                                 int count, int rows, long long ld) {
+    const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<long long>(count) * rows) return;
+    const long long r = t / count, i = t % count; // consecutive lanes read consecutive elements of one row
+    buf[i * rows + r] = q[r * ld + slots[i]];
+}
+
+__global__ void halo_unpack_kernel(double* __restrict__ q, const double* __restrict__ buf, int first, int count,
+                                   int rows, long long ld) {
+    const long long t = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (t >= static_cast<long long>(count) * rows) return;
+    const long long r = t / count, i = t % count;
+    q[r * ld + first + i] = buf[i * rows + r];
+}
+
+} // namespace bdg_dev
+
+using bdg_detail::arg_error;
+using bdg_detail::guard;
+using bdg_detail::hip_error;
+using bdg_detail::unstable_error;
+
+namespace {
+
+void hipCheck(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw hip_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count, size_t& total) {
+        release();
+        if (count == 0) return;
+        hipCheck(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)), "hipMalloc");
+        n = count;
+        total += count * sizeof(T);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+} // namespace
+
+struct bdg_sw2d {
+    const bdg_dev::KernelTable* kt = nullptr;
+    int N = 0, Np = 0, Nfp = 0, NFN = 0, K = 0, device = 0;
+    long long ld = 0;
+    double g = 9.81;
+    bool hasFilter = false, hasH = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t bytes = 0;
+    DevBuf<double> qA, qB, res, aux, geo, fgeo, ops, Hbuf, stage, partials, red2;
+    DevBuf<int> vmapP, perm, istage, sendSlots;
+    int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
+    double* qcur = nullptr;  // current state
+    double* qalt = nullptr;  // the other buffer
+    long long stageCount = 0; // LSERK stage counter (stage index = count % 5)
+    std::vector<int> permHost; // caller element -> device slot (empty = identity)
+
+    ~bdg_sw2d() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void use() const { hipCheck(hipSetDevice(device), "hipSetDevice"); }
+    size_t planeSize() const { return static_cast<size_t>(Np) * static_cast<size_t>(ld); }
+    const int* permDev() const { return perm.p; }
+
+    // host (rows, K) caller order -> device planes (padded / renumbered)
+    void uploadRows(const double* host, double* dev, int rows) {
+        const size_t n = static_cast<size_t>(rows) * K;
+        hipCheck(hipMemcpyAsync(stage.p, host, n * sizeof(double), hipMemcpyHostToDevice, stream), "H2D copy");
+        const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+        hipLaunchKernelGGL((bdg_dev::scatter_rows_kernel<double>), dim3(grid), dim3(256), 0, stream, stage.p, dev, rows,
+                           K, ld, permDev());
+        hipCheck(hipGetLastError(), "scatter_rows_kernel");
+        hipCheck(hipStreamSynchronize(stream), "upload sync"); // staging buffer is reused
+    }
+    void downloadRows(const double* dev, double* host, int rows) {
+        const size_t n = static_cast<size_t>(rows) * K;
+        const unsigned grid = static_cast<unsigned>((n + 255) / 256);
+        hipLaunchKernelGGL((bdg_dev::gather_rows_kernel<double>), dim3(grid), dim3(256), 0, stream, dev, stage.p, rows,
+                           K, ld, permDev());
+        hipCheck(hipGetLastError(), "gather_rows_kernel");
+        hipCheck(hipMemcpyAsync(host, stage.p, n * sizeof(double), hipMemcpyDeviceToHost, stream), "D2H copy");
+        hipCheck(hipStreamSynchronize(stream), "download sync");
+    }
+
+    bdg_dev::StageParams baseParams() const {
+        bdg_dev::StageParams p{};
+        p.geo = geo.p;
+        p.fgeo = fgeo.p;
+        p.vmapP = vmapP.p;
+        p.ops = ops.p;
+        p.ld = ld;
+        p.kbegin = 0;
+        p.kend = numOwned;
+        p.g = g;
+        return p;
+    }
+
+    void launchRhs(const double* qin, double* out, bool filter) {
+        if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
+        bdg_dev::StageParams p = baseParams();
+        p.qin = qin;
+        p.rhs = out;
+        hipCheck(kt->stage(bdg_dev::MODE_RHS, filter, p, stream), "sw2d_stage_kernel<RHS>");
+    }
+
+    // part: 0 = interior elements only (no ghost dependency; state not advanced),
+    //       1 = partition-boundary elements, then advance; 2 = all owned elements, then advance.
+    void launchLserkStage(int part = 2) {
+        const int s = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
+        bdg_dev::StageParams p = baseParams();
+        if (part == 0) p.kend = numInterior;
+        if (part == 1) p.kbegin = numInterior;
+        p.qin = qcur;
+        p.qout = qalt;
+        p.res = res.p;
+        p.ca = blitzdg::LSERK4::rk4a[s];
+        p.cb = blitzdg::LSERK4::rk4b[s];
+        p.cc = dtStage;
+        hipCheck(kt->stage(bdg_dev::MODE_LSERK, false, p, stream), "sw2d_stage_kernel<LSERK>");
+        if (part == 0) return;
+        std::swap(qcur, qalt);
+        ++stageCount;
+    }
+    double dtStage = 0.0;
+
+    // q1 = q + dt/2 R(q);  q = q + dt R(q1)   (reference src/sw2d-simple/main.cpp:132-151)
+    void launchRk2Step(double dt, bool filter) {
+        if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
+        bdg_dev::StageParams p = baseParams();
+        p.qin = qcur; p.qbase = qcur; p.qout = aux.p;
+        p.ca = 1.0; p.cb = 0.0; p.cc = 0.5 * dt;
+        hipCheck(kt->stage(bdg_dev::MODE_COMBINE, filter, p, stream), "sw2d_stage_kernel<COMBINE>");
+        p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
+        p.ca = 1.0; p.cb = 0.0; p.cc = dt;
+        hipCheck(kt->stage(bdg_dev::MODE_COMBINE, filter, p, stream), "sw2d_stage_kernel<COMBINE>");
+        std::swap(qcur, qalt);
+    }
+
+    // Returns {max |Fscale|*spd, max |eta|}; NaN if any entry is NaN.
+    void reduceDt(double out[2]) {
+        const int nblocks = (numOwned + 255) / 256;
+        hipCheck(kt->dt(qcur, fgeo.p + 2 * static_cast<size_t>(NFN) * ld, hasH ? Hbuf.p : nullptr, ld, numOwned, g, partials.p,
+                        stream), "sw2d_dt_kernel");
+        hipLaunchKernelGGL(bdg_dev::sw2d_reduce_kernel, dim3(1), dim3(256), 0, stream, partials.p, nblocks, red2.p);
+        hipCheck(hipGetLastError(), "sw2d_reduce_kernel");
+        hipCheck(hipMemcpyAsync(out, red2.p, 2 * sizeof(double), hipMemcpyDeviceToHost, stream), "D2H copy");
+        hipCheck(hipStreamSynchronize(stream), "reduce sync");
+    }
+};
+
+namespace {
+
+// Breadth-first (Cuthill-McKee style) renumbering from the face-neighbour graph:
+// neighbours end up within O(sqrt(K)) slots of each other, so the trace gather of
+// a wave hits lines its own or nearby waves stream. perm[k] = device slot.
+std::vector<int> bfsOrder(const int* vmapP, int K, int Np, int Nfp) {
+    std::vector<int> perm(K, -1);
+    int next = 0;
+    std::vector<int> frontier, nextFrontier;
+    for (int seed = 0; seed < K; ++seed) {
+        if (perm[seed] >= 0) continue;
+        perm[seed] = next++;
+        frontier.assign(1, seed);
+        while (!frontier.empty()) {
+            nextFrontier.clear();
+            for (int k : frontier)
+                for (int f = 0; f < 3; ++f) {
+                    const int k2 = vmapP[(static_cast<size_t>(k) * 3 + f) * Nfp] / Np;
+                    if (k2 >= 0 && k2 < K && perm[k2] < 0) {
+                        perm[k2] = next++;
+                        nextFrontier.push_back(k2);
+                    }
+                }
+            frontier.swap(nextFrontier);
+        }
+    }
+    return perm;
+}
+
+bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
+    if (d.order < 1 || d.order > BDG_SW2D_MAX_ORDER)
+        throw arg_error("bdg_sw2d_create: order must be 1.." + std::to_string(BDG_SW2D_MAX_ORDER) +
+                        " for the register-resident kernels");
+    if (d.num_elements < 1) throw arg_error("bdg_sw2d_create: num_elements must be >= 1");
+    if (!d.Dr || !d.Ds || !d.Lift || !d.rx || !d.sx || !d.ry || !d.sy || !d.nx || !d.ny || !d.Fscale || !d.vmapP)
+        throw arg_error("bdg_sw2d_create: a required table pointer is NULL");
+    if (d.num_wall < 0 || (d.num_wall > 0 && !d.mapW)) throw arg_error("bdg_sw2d_create: bad wall-node list");
+
+    const bdg_dev::KernelTable* kt = bdg_dev::kernel_table(d.order);
+    if (!kt) throw arg_error("bdg_sw2d_create: no kernels compiled for this order");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        throw hip_error("bdg_sw2d_create: no HIP device available (the sw2d path has no CPU fallback)");
+    if (d.device < 0 || d.device >= ndev) throw arg_error("bdg_sw2d_create: device ordinal out of range");
+
+    auto s = std::unique_ptr<bdg_sw2d>(new bdg_sw2d());
+    s->kt = kt;
+    s->N = d.order; s->Np = kt->Np; s->Nfp = kt->Nfp; s->NFN = 3 * kt->Nfp; s->K = d.num_elements;
+    s->device = d.device;
+    s->g = d.g;
+    s->ld = (static_cast<long long>(s->K) + 63) / 64 * 64;
+    s->numInterior = s->numOwned = s->K;
+    const int Np = s->Np, Nfp = s->Nfp, NFN = s->NFN, K = s->K;
+    const long long ld = s->ld;
+    if (static_cast<long long>(Np) * ld > 2147483647LL)
+        throw arg_error("bdg_sw2d_create: Np*K exceeds the 32-bit gather offsets");
+
+    // ---- validate the index tables on the host before anything touches the GPU
+    const size_t nFaceNodes = static_cast<size_t>(NFN) * K;
+    if (d.vmapM)
+        for (int k = 0; k < K; ++k)
+            for (int f = 0; f < 3; ++f)
+                for (int n = 0; n < Nfp; ++n)
+                    if (d.vmapM[(static_cast<size_t>(k) * 3 + f) * Nfp + n] != kt->fmask(f, n) + Np * k)
+                        throw arg_error("bdg_sw2d_create: vmapM does not follow the warp&blend face-node ordering "
+                                        "(Fmask) these kernels are specialised for");
+    const long long totalNodes = static_cast<long long>(Np) * K;
+    for (size_t i = 0; i < nFaceNodes; ++i)
+        if (d.vmapP[i] < 0 || d.vmapP[i] >= totalNodes) throw arg_error("bdg_sw2d_create: vmapP entry out of range");
+    for (int i = 0; i < d.num_wall; ++i)
+        if (d.mapW[i] < 0 || static_cast<size_t>(d.mapW[i]) >= nFaceNodes)
+            throw arg_error("bdg_sw2d_create: wall-node index out of range");
+
+    if (d.flags & BDG_SW2D_REORDER) s->permHost = bfsOrder(d.vmapP, K, Np, Nfp);
+
+    s->use();
+    hipCheck(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
+    hipCheck(hipEventCreate(&s->ev0), "hipEventCreate");
+    hipCheck(hipEventCreate(&s->ev1), "hipEventCreate");
+
+    const size_t plane3 = 3 * s->planeSize();
+    s->qA.alloc(plane3, s->bytes);
+    s->qB.alloc(plane3, s->bytes);
+    s->res.alloc(plane3, s->bytes);
+    s->aux.alloc(plane3, s->bytes);
+    s->geo.alloc(4 * s->planeSize(), s->bytes);
+    s->fgeo.alloc(3 * static_cast<size_t>(NFN) * ld, s->bytes);
+    s->vmapP.alloc(static_cast<size_t>(NFN) * ld, s->bytes);
+    s->ops.alloc(kt->ldsDoubles, s->bytes);
+    s->stage.alloc(static_cast<size_t>(std::max(Np, NFN)) * K, s->bytes);
+    s->istage.alloc(static_cast<size_t>(NFN) * K, s->bytes);
+    s->partials.alloc(2 * static_cast<size_t>((K + 255) / 256), s->bytes);
+    s->red2.alloc(2, s->bytes);
+    if (!s->permHost.empty()) {
+        s->perm.alloc(K, s->bytes);
+        hipCheck(hipMemcpy(s->perm.p, s->permHost.data(), sizeof(int) * K, hipMemcpyHostToDevice), "perm upload");
+    }
+    for (auto* b : {&s->qA, &s->qB, &s->res, &s->aux, &s->geo, &s->fgeo})
+        hipCheck(hipMemsetAsync(b->p, 0, b->n * sizeof(double), s->stream), "hipMemset");
+    hipCheck(hipMemsetAsync(s->vmapP.p, 0, s->vmapP.n * sizeof(int), s->stream), "hipMemset");
+    s->qcur = s->qA.p;
+    s->qalt = s->qB.p;
+
+    // ---- operator image: [Dr,Ds interleaved | Lift | Filter]
+    std::vector<double> img(kt->ldsDoubles, 0.0);
+    for (int i = 0; i < Np * Np; ++i) {
+        img[2 * i] = d.Dr[i];
+        img[2 * i + 1] = d.Ds[i];
+    }
+    std::copy(d.Lift, d.Lift + static_cast<size_t>(Np) * NFN, img.begin() + 2 * Np * Np);
+    if (d.Filter) {
+        std::copy(d.Filter, d.Filter + static_cast<size_t>(Np) * Np, img.begin() + 2 * Np * Np + Np * NFN);
+        s->hasFilter = true;
+    }
+    hipCheck(hipMemcpyAsync(s->ops.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, s->stream),
+             "ops upload");
+    hipCheck(hipStreamSynchronize(s->stream), "ops sync");
+
+    // ---- geometry planes
+    const size_t pl = s->planeSize();
+    s->uploadRows(d.rx, s->geo.p, Np);
+    s->uploadRows(d.sx, s->geo.p + pl, Np);
+    s->uploadRows(d.ry, s->geo.p + 2 * pl, Np);
+    s->uploadRows(d.sy, s->geo.p + 3 * pl, Np);
+    const size_t fpl = static_cast<size_t>(NFN) * ld;
+    s->uploadRows(d.nx, s->fgeo.p, NFN);
+    s->uploadRows(d.ny, s->fgeo.p + fpl, NFN);
+    s->uploadRows(d.Fscale, s->fgeo.p + 2 * fpl, NFN);
+
+    // ---- gather offsets: reference numbering (n' + Np*k') -> n'*ld + slot(k'), as (NFN, K) rows;
+    //      wall nodes are stored as -(offset+1).
+    {
+        std::vector<int> rows(nFaceNodes);
+        const int* perm = s->permHost.empty() ? nullptr : s->permHost.data();
+        for (int k = 0; k < K; ++k)
+            for (int j = 0; j < NFN; ++j) {
+                const int v = d.vmapP[static_cast<size_t>(k) * NFN + j];
+                const int n2 = v % Np, k2 = v / Np;
+                rows[static_cast<size_t>(j) * K + k] = static_cast<int>(n2 * ld + (perm ? perm[k2] : k2));
+            }
+        for (int i = 0; i < d.num_wall; ++i) {
+            const int w = d.mapW[i], k = w / NFN, j = w % NFN;
+            int& e = rows[static_cast<size_t>(j) * K + k];
+            if (e >= 0) e = -(e + 1);
+        }
+        hipCheck(hipMemcpyAsync(s->istage.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice, s->stream),
+                 "vmapP upload");
+        const unsigned grid = static_cast<unsigned>((rows.size() + 255) / 256);
+        hipLaunchKernelGGL((bdg_dev::scatter_rows_kernel<int>), dim3(grid), dim3(256), 0, s->stream, s->istage.p,
+                           s->vmapP.p, NFN, K, ld, s->permDev());
+        hipCheck(hipGetLastError(), "scatter_rows_kernel<int>");
+        hipCheck(hipStreamSynchronize(s->stream), "vmapP sync");
+    }
+    s->istage.release();
+    return s.release();
+}
+
+void requireSolver(const bdg_sw2d* s, const char* fn) {
+    if (!s) throw arg_error(std::string(fn) + ": solver handle is NULL");
+}
+
+} // namespace
+
+extern "C" {
+
+int bdg_sw2d_create(const bdg_sw2d_desc* desc, bdg_sw2d** out) {
+    return guard([&] {
+        if (!desc || !out) throw arg_error("bdg_sw2d_create: NULL argument");
+        *out = createSolver(*desc);
+    });
+}
+
+int bdg_sw2d_create_from_nodes(const bdg_trinodes* nodes, double g, int device, int flags, bdg_sw2d** out) {
+    return guard([&] {
+        if (!nodes || !out) throw arg_error("bdg_sw2d_create_from_nodes: NULL argument");
+        const blitzdg::TriangleNodesProvisioner& p = nodes->prov;
+        bdg_sw2d_desc d{};
+        d.order = p.get_NOrder();
+        d.num_elements = p.get_NumElements();
+        d.Dr = p.get_Dr().data(); d.Ds = p.get_Ds().data(); d.Lift = p.get_Lift().data();
+        d.Filter = nodes->hasFilter ? p.get_Filter().data() : nullptr;
+        d.rx = p.get_rx().data(); d.sx = p.get_sx().data(); d.ry = p.get_ry().data(); d.sy = p.get_sy().data();
+        d.nx = p.get_nx().data(); d.ny = p.get_ny().data(); d.Fscale = p.get_Fscale().data();
+        d.vmapM = p.get_vmapM().data(); d.vmapP = p.get_vmapP().data();
+        const auto& bc = p.get_bcMap();
+        const auto it = bc.find(blitzdg::BCTag::Wall);
+        if (it != bc.end()) { d.mapW = it->second.data(); d.num_wall = static_cast<int>(it->second.size()); }
+        d.g = g; d.device = device; d.flags = flags;
+        *out = createSolver(d);
+    });
+}
+
+void bdg_sw2d_destroy(bdg_sw2d* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    delete s;
+}
+
+int bdg_sw2d_set_state(bdg_sw2d* s, const double* h, const double* hu, const double* hv) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_set_state");
+        if (!h || !hu || !hv) throw arg_error("bdg_sw2d_set_state: NULL field");
+        s->use();
+        const size_t pl = s->planeSize();
+        s->uploadRows(h, s->qcur, s->Np);
+        s->uploadRows(hu, s->qcur + pl, s->Np);
+        s->uploadRows(hv, s->qcur + 2 * pl, s->Np);
+        hipCheck(hipMemsetAsync(s->res.p, 0, s->res.n * sizeof(double), s->stream), "hipMemset");
+        s->stageCount = 0;
+        hipCheck(hipStreamSynchronize(s->stream), "set_state sync");
+    });
+}
+
+int bdg_sw2d_get_state(bdg_sw2d* s, double* h, double* hu, double* hv) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_get_state");
+        if (!h || !hu || !hv) throw arg_error("bdg_sw2d_get_state: NULL field");
+        s->use();
+        const size_t pl = s->planeSize();
+        s->downloadRows(s->qcur, h, s->Np);
+        s->downloadRows(s->qcur + pl, hu, s->Np);
+        s->downloadRows(s->qcur + 2 * pl, hv, s->Np);
+    });
+}
+
+int bdg_sw2d_set_bathymetry(bdg_sw2d* s, const double* H) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_set_bathymetry");
+        s->use();
+        if (!H) { s->hasH = false; return; }
+        if (!s->Hbuf.p) s->Hbuf.alloc(s->planeSize(), s->bytes);
+        hipCheck(hipMemsetAsync(s->Hbuf.p, 0, s->Hbuf.n * sizeof(double), s->stream), "hipMemset");
+        s->uploadRows(H, s->Hbuf.p, s->Np);
+        s->hasH = true;
+    });
+}
+
+int bdg_sw2d_rhs(bdg_sw2d* s, const double* h, const double* hu, const double* hv, double* r1, double* r2,
+                 double* r3, int filter) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_rhs");
+        if (!h || !hu || !hv || !r1 || !r2 || !r3) throw arg_error("bdg_sw2d_rhs: NULL field");
+        s->use();
+        const size_t pl = s->planeSize();
+        // the inactive state buffer is scratch between steps
+        s->uploadRows(h, s->qalt, s->Np);
+        s->uploadRows(hu, s->qalt + pl, s->Np);
+        s->uploadRows(hv, s->qalt + 2 * pl, s->Np);
+        s->launchRhs(s->qalt, s->aux.p, filter != 0);
+        s->downloadRows(s->aux.p, r1, s->Np);
+        s->downloadRows(s->aux.p + pl, r2, s->Np);
+        s->downloadRows(s->aux.p + 2 * pl, r3, s->Np);
+    });
+}
+
+int bdg_sw2d_lserk4_stages(bdg_sw2d* s, double dt, int num_stages) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_lserk4_stages");
+        if (num_stages < 0) throw arg_error("bdg_sw2d_lserk4_stages: num_stages < 0");
+        s->use();
+        s->dtStage = dt;
+        for (int i = 0; i < num_stages; ++i) s->launchLserkStage();
+    });
+}
+
+int bdg_sw2d_step_lserk4(bdg_sw2d* s, double dt, int num_steps) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_step_lserk4");
+        if (num_steps < 0) throw arg_error("bdg_sw2d_step_lserk4: num_steps < 0");
+        if (s->stageCount % blitzdg::LSERK4::numStages != 0)
+            throw arg_error("bdg_sw2d_step_lserk4: a previous step was left part-way through its stages");
+        s->use();
+        s->dtStage = dt;
+        for (int i = 0; i < num_steps * blitzdg::LSERK4::numStages; ++i) s->launchLserkStage();
+    });
+}
+
+int bdg_sw2d_step_rk2(bdg_sw2d* s, double dt, int num_steps, int filter) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_step_rk2");
+        if (num_steps < 0) throw arg_error("bdg_sw2d_step_rk2: num_steps < 0");
+        s->use();
+        for (int i = 0; i < num_steps; ++i) s->launchRk2Step(dt, filter != 0);
+    });
+}
+
+int bdg_sw2d_compute_dt(bdg_sw2d* s, double cfl, double* dt, double* eta_max) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_compute_dt");
+        s->use();
+        double r[2];
+        s->reduceDt(r);
+        if (eta_max) *eta_max = r[1];
+        if (dt) *dt = cfl / ((s->N + 1) * (s->N + 1) * 0.5 * r[0]);
+        if (std::isnan(r[0]) || std::isnan(r[1]) || std::fabs(r[1]) > 1e8)
+            throw unstable_error("A numerical instability has occurred!");
+    });
+}
+
+int bdg_sw2d_run_adaptive(bdg_sw2d* s, double cfl, double final_time, int max_steps, int filter, double* t_inout,
+                          double* dt_inout, int* steps_done) {
+    int done = 0;
+    const int rc = guard([&] {
+        requireSolver(s, "bdg_sw2d_run_adaptive");
+        if (!t_inout || !dt_inout) throw arg_error("bdg_sw2d_run_adaptive: NULL argument");
+        s->use();
+        double t = *t_inout, dt = *dt_inout;
+        while (t < final_time && (max_steps <= 0 || done < max_steps)) {
+            s->launchRk2Step(dt, filter != 0);
+            double r[2];
+            s->reduceDt(r);
+            if (std::isnan(r[0]) || std::isnan(r[1]) || std::fabs(r[1]) > 1e8)
+                throw unstable_error("A numerical instability has occurred!");
+            dt = cfl / ((s->N + 1) * (s->N + 1) * 0.5 * r[0]);
+            t += dt;
+            ++done;
+            *t_inout = t;
+            *dt_inout = dt;
+        }
+    });
+    if (steps_done) *steps_done = done;
+    return rc;
+}
+
+int bdg_sw2d_synchronize(bdg_sw2d* s) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_synchronize");
+        s->use();
+        hipCheck(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+    });
+}
+
+int bdg_sw2d_time_lserk4_stages(bdg_sw2d* s, double dt, int num_stages, float* ms_per_launch) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_time_lserk4_stages");
+        if (num_stages < 1 || !ms_per_launch) throw arg_error("bdg_sw2d_time_lserk4_stages: bad argument");
+        s->use();
+        s->dtStage = dt;
+        hipCheck(hipEventRecord(s->ev0, s->stream), "hipEventRecord");
+        for (int i = 0; i < num_stages; ++i) s->launchLserkStage();
+        hipCheck(hipEventRecord(s->ev1, s->stream), "hipEventRecord");
+        hipCheck(hipEventSynchronize(s->ev1), "hipEventSynchronize");
+        float ms = 0.f;
+        hipCheck(hipEventElapsedTime(&ms, s->ev0, s->ev1), "hipEventElapsedTime");
+        *ms_per_launch = ms / num_stages;
+    });
+}
+
+int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const int* send_elements, int num_send) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_set_partition");
+        if (!s->permHost.empty()) throw arg_error("bdg_sw2d_set_partition: not available together with BDG_SW2D_REORDER");
+        if (num_interior < 0 || num_interior > num_owned || num_owned > s->K || num_send < 0 ||
+            (num_send > 0 && !send_elements))
+            throw arg_error("bdg_sw2d_set_partition: need 0 <= num_interior <= num_owned <= K");
+        for (int i = 0; i < num_send; ++i)
+            if (send_elements[i] < 0 || send_elements[i] >= num_owned)
+                throw arg_error("bdg_sw2d_set_partition: send element is not an owned element");
+        s->use();
+        s->sendSlots.release();
+        if (num_send > 0) {
+            s->sendSlots.alloc(num_send, s->bytes);
+            hipCheck(hipMemcpy(s->sendSlots.p, send_elements, sizeof(int) * num_send, hipMemcpyHostToDevice),
+                     "send list upload");
+        }
+        s->numInterior = num_interior;
+        s->numOwned = num_owned;
+        s->numSend = num_send;
+    });
+}
+
+int bdg_sw2d_halo_doubles_per_element(const bdg_sw2d* s) { return s ? 3 * s->Np : -1; }
+
+int bdg_sw2d_halo_pack(bdg_sw2d* s, void* send_buffer) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_halo_pack");
+        if (s->numSend == 0) return;
+        if (!send_buffer) throw arg_error("bdg_sw2d_halo_pack: buffer is NULL");
+        s->use();
+        const int rows = 3 * s->Np;
+        const long long n = static_cast<long long>(s->numSend) * rows;
+        hipLaunchKernelGGL(bdg_dev::halo_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                           s->stream, s->qcur, static_cast<double*>(send_buffer), s->sendSlots.p, s->numSend, rows,
+                           s->ld);
+        hipCheck(hipGetLastError(), "halo_pack_kernel");
+    });
+}
+
+int bdg_sw2d_halo_unpack(bdg_sw2d* s, const void* recv_buffer) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_halo_unpack");
+        const int ghosts = s->K - s->numOwned;
+        if (ghosts == 0) return;
+        if (!recv_buffer) throw arg_error("bdg_sw2d_halo_unpack: buffer is NULL");
+        s->use();
+        const int rows = 3 * s->Np;
+        const long long n = static_cast<long long>(ghosts) * rows;
+        hipLaunchKernelGGL(bdg_dev::halo_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                           s->stream, s->qcur, static_cast<const double*>(recv_buffer), s->numOwned, ghosts, rows,
+                           s->ld);
+        hipCheck(hipGetLastError(), "halo_unpack_kernel");
+    });
+}
+
+int bdg_sw2d_lserk4_stage_part(bdg_sw2d* s, double dt, int part) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_lserk4_stage_part");
+        if (part < 0 || part > 2) throw arg_error("bdg_sw2d_lserk4_stage_part: part must be 0, 1 or 2");
+        s->use();
+        s->dtStage = dt;
+        s->launchLserkStage(part);
+    });
+}
+
+int bdg_sw2d_rhs_resident(bdg_sw2d* s, double* r1, double* r2, double* r3) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_rhs_resident");
+        if (!r1 || !r2 || !r3) throw arg_error("bdg_sw2d_rhs_resident: NULL output");
+        s->use();
+        const size_t pl = s->planeSize();
+        s->launchRhs(s->qcur, s->aux.p, false);
+        s->downloadRows(s->aux.p, r1, s->Np);
+        s->downloadRows(s->aux.p + pl, r2, s->Np);
+        s->downloadRows(s->aux.p + 2 * pl, r3, s->Np);
+    });
+}
+
+size_t bdg_sw2d_device_bytes(const bdg_sw2d* s) { return s ? s->bytes : 0; }
+void* bdg_sw2d_stream(bdg_sw2d* s) { return s ? static_cast<void*>(s->stream) : nullptr; }
+
+} // extern "C"

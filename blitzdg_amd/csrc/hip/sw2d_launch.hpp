@@ -1,0 +1,22 @@
+// Per-order launch table: each polynomial order is compiled in its own
+// translation unit (sw2d_order.hip with -DBDG_ORDER=N) so the fully unrolled
+// kernels build in parallel; the solver picks the table at run time.
+#pragma once
+#include "sw2d_kernels.hpp"
+
+namespace bdg_dev {
+
+struct KernelTable {
+    int order, Np, Nfp, ldsDoubles;
+    // mode: StageMode; launches one fused RHS(+stage update) pass over K elements.
+    hipError_t (*stage)(int mode, bool filter, const StageParams& p, hipStream_t stream);
+    // per-block partial maxima (2 doubles per block of 256 elements)
+    hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
+                     double* partials, hipStream_t stream);
+    // volume node index of face node (f, n), for validating the caller's vmapM
+    int (*fmask)(int f, int n);
+};
+
+const KernelTable* kernel_table(int order); // nullptr if the order is not compiled in
+
+} // namespace bdg_dev

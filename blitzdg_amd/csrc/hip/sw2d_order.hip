@@ -1,0 +1,52 @@
+// Instantiates the sw2d kernels for one polynomial order (-DBDG_ORDER=N).
+#include "sw2d_launch.hpp"
+
+#ifndef BDG_ORDER
+#error "compile with -DBDG_ORDER=<polynomial order>"
+#endif
+
+namespace bdg_dev {
+namespace {
+
+constexpr int kN = BDG_ORDER;
+constexpr int kBlock = 256;
+
+template <int MODE, bool FILTER>
+hipError_t launchStage(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sw2d_stage_kernel<kN, MODE, FILTER>), dim3(grid), dim3(kBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t stage(int mode, bool filter, const StageParams& p, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return filter ? launchStage<MODE_RHS, true>(p, stream) : launchStage<MODE_RHS, false>(p, stream);
+    case MODE_LSERK: return filter ? hipErrorInvalidValue : launchStage<MODE_LSERK, false>(p, stream);
+    case MODE_COMBINE:
+        return filter ? launchStage<MODE_COMBINE, true>(p, stream) : launchStage<MODE_COMBINE, false>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t dt(const double* q, const double* fscale, const double* H, long long ld, int K, double g, double* partials,
+              hipStream_t stream) {
+    const unsigned grid = static_cast<unsigned>((K + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sw2d_dt_kernel<kN>), dim3(grid), dim3(kBlock), 0, stream, q, fscale, H, ld, K, g, partials);
+    return hipGetLastError();
+}
+
+int fmaskOf(int f, int n) { return Elem<kN>::fmask(f, n); }
+
+} // namespace
+
+#define BDG_CAT2(a, b) a##b
+#define BDG_CAT(a, b) BDG_CAT2(a, b)
+// A host function (not a namespace-scope constant, which hipcc would also emit for
+// the device and then fail to resolve the host function pointers in).
+const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
+    static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, Elem<kN>::LDS_DOUBLES, &stage, &dt, &fmaskOf};
+    return &table;
+}
+
+} // namespace bdg_dev

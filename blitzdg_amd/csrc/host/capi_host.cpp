@@ -1,0 +1,287 @@
+// C ABI, host-setup group (see include/blitzdg_hip.h). Thin handles around the
+// C++ classes; tables are exported as borrowed views so the Python front end
+// (blitzdg_amd/pyblitzdg.py) can mirror the reference's boost::python module
+// (src/pyblitzdg/pyblitzdg.cpp:59-201) without copying on this side.
+#include "capi_internal.hpp"
+#include "blitzdg/Advec1d.hpp"
+#include "blitzdg/LSERK4.hpp"
+#include <algorithm>
+#include <cstring>
+
+using namespace blitzdg;
+
+namespace bdg_detail {
+thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+} // namespace bdg_detail
+
+using bdg_detail::guard;
+using bdg_detail::set_error;
+
+namespace {
+void view(bdg_table* out, const real_matrix_type& m) { *out = {m.data(), m.rows(), m.cols(), BDG_F64}; }
+void view(bdg_table* out, const index_matrix_type& m) { *out = {m.data(), m.rows(), m.cols(), BDG_I32}; }
+void view(bdg_table* out, const real_vector_type& v) { *out = {v.data(), v.size(), 1, BDG_F64}; }
+void view(bdg_table* out, const index_vector_type& v) { *out = {v.data(), v.size(), 1, BDG_I32}; }
+void view(bdg_table* out, const std::vector<index_type>& v) {
+    *out = {v.data(), static_cast<int>(v.size()), 1, BDG_I32};
+}
+void view2(bdg_table* out, const index_vector_type& v, int cols) {
+    *out = {v.data(), cols ? v.size() / cols : 0, cols, BDG_I32};
+}
+} // namespace
+
+extern "C" {
+
+const char* bdg_last_error(void) { return bdg_detail::g_last_error.c_str(); }
+int bdg_version(void) { return 100; }
+
+// ------------------------------------------------------------------ mesh
+
+int bdg_mesh_create(bdg_mesh** out) {
+    return guard([&] {
+        if (!out) throw bdg_detail::arg_error("bdg_mesh_create: out is NULL");
+        *out = new bdg_mesh();
+    });
+}
+
+void bdg_mesh_destroy(bdg_mesh* mesh) { delete mesh; }
+
+int bdg_mesh_read(bdg_mesh* mesh, const char* path) {
+    return guard([&] {
+        if (!mesh || !path) throw bdg_detail::arg_error("bdg_mesh_read: NULL argument");
+        mesh->mgr.readMesh(path);
+    });
+}
+
+int bdg_mesh_build(bdg_mesh* mesh, const int* etov, int K, const double* vert, int Nv, int dim) {
+    return guard([&] {
+        if (!mesh || !etov || !vert || K < 1 || Nv < 3) throw bdg_detail::arg_error("bdg_mesh_build: bad argument");
+        mesh->mgr.buildMesh(etov, K, vert, Nv, dim);
+    });
+}
+
+int bdg_mesh_build_box(bdg_mesh* mesh, int nx, int ny, double x0, double x1, double y0, double y1,
+                       unsigned long long seed) {
+    return guard([&] {
+        if (!mesh) throw bdg_detail::arg_error("bdg_mesh_build_box: mesh is NULL");
+        mesh->mgr.buildBoxMesh(nx, ny, x0, x1, y0, y1, seed);
+    });
+}
+
+int bdg_mesh_set_bctype(bdg_mesh* mesh, const int* bctype, int n) {
+    return guard([&] {
+        if (!mesh || !bctype) throw bdg_detail::arg_error("bdg_mesh_set_bctype: NULL argument");
+        mesh->mgr.set_BCType(bctype, n);
+    });
+}
+
+int bdg_mesh_partition(bdg_mesh* mesh, int nparts) {
+    return guard([&] {
+        if (!mesh) throw bdg_detail::arg_error("bdg_mesh_partition: mesh is NULL");
+        mesh->mgr.partitionMesh(nparts);
+    });
+}
+
+int bdg_mesh_num_elements(const bdg_mesh* mesh) { return mesh ? mesh->mgr.get_NumElements() : -1; }
+int bdg_mesh_num_verts(const bdg_mesh* mesh) { return mesh ? mesh->mgr.get_NumVerts() : -1; }
+
+int bdg_mesh_table(const bdg_mesh* mesh, int which, bdg_table* out) {
+    return guard([&] {
+        if (!mesh || !out) throw bdg_detail::arg_error("bdg_mesh_table: NULL argument");
+        const MeshManager& m = mesh->mgr;
+        switch (which) {
+        case BDG_MESH_VERTICES: *out = {m.get_Vertices().data(), m.get_NumVerts(), m.get_Dim(), BDG_F64}; break;
+        case BDG_MESH_ELEMENTS: view2(out, m.get_Elements(), 3); break;
+        case BDG_MESH_ETOE: view2(out, m.get_EToE(), 3); break;
+        case BDG_MESH_ETOF: view2(out, m.get_EToF(), 3); break;
+        case BDG_MESH_BCTYPE: view2(out, m.get_BCType(), 3); break;
+        case BDG_MESH_EPART: view(out, m.get_ElementPartitionMap()); break;
+        case BDG_MESH_NPART: view(out, m.get_VertexPartitionMap()); break;
+        default: throw bdg_detail::arg_error("bdg_mesh_table: unknown table id");
+        }
+    });
+}
+
+// ------------------------------------------------------------------ triangle nodes
+
+int bdg_trinodes_create(int order, const bdg_mesh* mesh, bdg_trinodes** out) {
+    return guard([&] {
+        if (!mesh || !out) throw bdg_detail::arg_error("bdg_trinodes_create: NULL argument");
+        if (mesh->mgr.get_NumElements() < 1) throw bdg_detail::arg_error("bdg_trinodes_create: mesh is empty");
+        *out = new bdg_trinodes{TriangleNodesProvisioner(order, mesh->mgr)};
+    });
+}
+
+void bdg_trinodes_destroy(bdg_trinodes* nodes) { delete nodes; }
+
+int bdg_trinodes_build_filter(bdg_trinodes* nodes, double Nc, int s) {
+    return guard([&] {
+        if (!nodes) throw bdg_detail::arg_error("bdg_trinodes_build_filter: nodes is NULL");
+        nodes->prov.buildFilter(Nc, s);
+        nodes->hasFilter = true;
+    });
+}
+
+int bdg_trinodes_build_bchash(bdg_trinodes* nodes, const int* bctype, int n) {
+    return guard([&] {
+        if (!nodes || !bctype) throw bdg_detail::arg_error("bdg_trinodes_build_bchash: NULL argument");
+        index_vector_type bc(n);
+        std::copy(bctype, bctype + n, bc.begin());
+        nodes->prov.buildBCHash(bc);
+    });
+}
+
+int bdg_trinodes_set_coordinates(bdg_trinodes* nodes, const double* x, const double* y) {
+    return guard([&] {
+        if (!nodes || !x || !y) throw bdg_detail::arg_error("bdg_trinodes_set_coordinates: NULL argument");
+        nodes->prov.setCoordinates(x, y);
+    });
+}
+
+int bdg_trinodes_dims(const bdg_trinodes* nodes, int* order, int* np, int* nfp, int* K) {
+    return guard([&] {
+        if (!nodes) throw bdg_detail::arg_error("bdg_trinodes_dims: nodes is NULL");
+        if (order) *order = nodes->prov.get_NOrder();
+        if (np) *np = nodes->prov.get_NumLocalPoints();
+        if (nfp) *nfp = nodes->prov.get_NumFacePoints();
+        if (K) *K = nodes->prov.get_NumElements();
+    });
+}
+
+int bdg_trinodes_table(const bdg_trinodes* nodes, int which, bdg_table* out) {
+    return guard([&] {
+        if (!nodes || !out) throw bdg_detail::arg_error("bdg_trinodes_table: NULL argument");
+        const TriangleNodesProvisioner& p = nodes->prov;
+        switch (which) {
+        case BDG_TRI_R: view(out, p.get_rGrid()); break;
+        case BDG_TRI_S: view(out, p.get_sGrid()); break;
+        case BDG_TRI_X: view(out, p.get_xGrid()); break;
+        case BDG_TRI_Y: view(out, p.get_yGrid()); break;
+        case BDG_TRI_V: view(out, p.get_V()); break;
+        case BDG_TRI_VINV: view(out, p.get_Vinv()); break;
+        case BDG_TRI_DR: view(out, p.get_Dr()); break;
+        case BDG_TRI_DS: view(out, p.get_Ds()); break;
+        case BDG_TRI_DRW: view(out, p.get_Drw()); break;
+        case BDG_TRI_DSW: view(out, p.get_Dsw()); break;
+        case BDG_TRI_LIFT: view(out, p.get_Lift()); break;
+        case BDG_TRI_FILTER: view(out, p.get_Filter()); break;
+        case BDG_TRI_J: view(out, p.get_J()); break;
+        case BDG_TRI_RX: view(out, p.get_rx()); break;
+        case BDG_TRI_RY: view(out, p.get_ry()); break;
+        case BDG_TRI_SX: view(out, p.get_sx()); break;
+        case BDG_TRI_SY: view(out, p.get_sy()); break;
+        case BDG_TRI_NX: view(out, p.get_nx()); break;
+        case BDG_TRI_NY: view(out, p.get_ny()); break;
+        case BDG_TRI_FSCALE: view(out, p.get_Fscale()); break;
+        case BDG_TRI_FMASK: view(out, p.get_Fmask()); break;
+        case BDG_TRI_FX: view(out, p.get_Fx()); break;
+        case BDG_TRI_FY: view(out, p.get_Fy()); break;
+        case BDG_TRI_VMAPM: view(out, p.get_vmapM()); break;
+        case BDG_TRI_VMAPP: view(out, p.get_vmapP()); break;
+        case BDG_TRI_MAPP: view(out, p.get_mapP()); break;
+        case BDG_TRI_VMAPB: view(out, p.get_vmapB()); break;
+        case BDG_TRI_MAPB: view(out, p.get_mapB()); break;
+        case BDG_TRI_GATHER: view(out, p.get_gather()); break;
+        case BDG_TRI_SCATTER: view(out, p.get_scatter()); break;
+        default: throw bdg_detail::arg_error("bdg_trinodes_table: unknown table id");
+        }
+    });
+}
+
+int bdg_trinodes_bcmap_num_tags(const bdg_trinodes* nodes) {
+    return nodes ? static_cast<int>(nodes->prov.get_bcMap().size()) : -1;
+}
+
+int bdg_trinodes_bcmap_tags(const bdg_trinodes* nodes, int* tags, int capacity) {
+    return guard([&] {
+        if (!nodes || !tags) throw bdg_detail::arg_error("bdg_trinodes_bcmap_tags: NULL argument");
+        std::vector<int> keys;
+        for (const auto& kv : nodes->prov.get_bcMap()) keys.push_back(kv.first);
+        std::sort(keys.begin(), keys.end());
+        if (static_cast<int>(keys.size()) > capacity) throw bdg_detail::arg_error("bdg_trinodes_bcmap_tags: capacity too small");
+        std::copy(keys.begin(), keys.end(), tags);
+    });
+}
+
+int bdg_trinodes_bcmap_nodes(const bdg_trinodes* nodes, int tag, const int** out, int* count) {
+    return guard([&] {
+        if (!nodes || !out || !count) throw bdg_detail::arg_error("bdg_trinodes_bcmap_nodes: NULL argument");
+        const auto& map = nodes->prov.get_bcMap();
+        const auto it = map.find(tag);
+        if (it == map.end()) { *out = nullptr; *count = 0; return; }
+        *out = it->second.data();
+        *count = static_cast<int>(it->second.size());
+    });
+}
+
+// ------------------------------------------------------------------ 1-D nodes
+
+int bdg_nodes1d_create(int order, int K, double xmin, double xmax, bdg_nodes1d** out) {
+    return guard([&] {
+        if (!out || order < 1 || K < 1 || !(xmax > xmin)) throw bdg_detail::arg_error("bdg_nodes1d_create: bad argument");
+        *out = new bdg_nodes1d{Nodes1DProvisioner(order, K, xmin, xmax)};
+    });
+}
+
+void bdg_nodes1d_destroy(bdg_nodes1d* nodes) { delete nodes; }
+
+int bdg_nodes1d_build_nodes(bdg_nodes1d* nodes) {
+    return guard([&] {
+        if (!nodes) throw bdg_detail::arg_error("bdg_nodes1d_build_nodes: nodes is NULL");
+        nodes->prov.buildNodes();
+    });
+}
+
+int bdg_nodes1d_compute_jacobian(bdg_nodes1d* nodes) {
+    return guard([&] {
+        if (!nodes) throw bdg_detail::arg_error("bdg_nodes1d_compute_jacobian: nodes is NULL");
+        nodes->prov.computeJacobian();
+    });
+}
+
+int bdg_nodes1d_map_i(const bdg_nodes1d* nodes) { return nodes ? nodes->prov.get_mapI() : -1; }
+int bdg_nodes1d_map_o(const bdg_nodes1d* nodes) { return nodes ? nodes->prov.get_mapO() : -1; }
+
+int bdg_nodes1d_table(const bdg_nodes1d* nodes, int which, bdg_table* out) {
+    return guard([&] {
+        if (!nodes || !out) throw bdg_detail::arg_error("bdg_nodes1d_table: NULL argument");
+        const Nodes1DProvisioner& p = nodes->prov;
+        switch (which) {
+        case BDG_N1D_R: view(out, p.get_rGrid()); break;
+        case BDG_N1D_X: view(out, p.get_xGrid()); break;
+        case BDG_N1D_V: view(out, p.get_V()); break;
+        case BDG_N1D_VINV: view(out, p.get_Vinv()); break;
+        case BDG_N1D_DR: view(out, p.get_Dr()); break;
+        case BDG_N1D_LIFT: view(out, p.get_Lift()); break;
+        case BDG_N1D_J: view(out, p.get_J()); break;
+        case BDG_N1D_RX: view(out, p.get_rx()); break;
+        case BDG_N1D_NX: view(out, p.get_nx()); break;
+        case BDG_N1D_FMASK: view(out, p.get_Fmask()); break;
+        case BDG_N1D_FX: view(out, p.get_Fx()); break;
+        case BDG_N1D_FSCALE: view(out, p.get_Fscale()); break;
+        case BDG_N1D_ETOV: view(out, p.get_EToV()); break;
+        case BDG_N1D_ETOE: view(out, p.get_EToE()); break;
+        case BDG_N1D_ETOF: view(out, p.get_EToF()); break;
+        case BDG_N1D_VMAPM: view(out, p.get_vmapM()); break;
+        case BDG_N1D_VMAPP: view(out, p.get_vmapP()); break;
+        default: throw bdg_detail::arg_error("bdg_nodes1d_table: unknown table id");
+        }
+    });
+}
+
+int bdg_lserk4_num_stages(void) { return LSERK4::numStages; }
+const double* bdg_lserk4_a(void) { return LSERK4::rk4a; }
+const double* bdg_lserk4_b(void) { return LSERK4::rk4b; }
+
+int bdg_advec1d_run(int order, int K, double xmin, double xmax, double c, double cfl, double final_time,
+                    double* max_error, int* num_steps) {
+    return guard([&] {
+        if (!max_error || order < 1 || K < 1 || c == 0.0) throw bdg_detail::arg_error("bdg_advec1d_run: bad argument");
+        index_type steps = 0;
+        *max_error = advec1d::run(order, K, xmin, xmax, c, cfl, final_time, &steps);
+        if (num_steps) *num_steps = steps;
+    });
+}
+
+} // extern "C"

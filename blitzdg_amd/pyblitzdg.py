@@ -1,0 +1,243 @@
+"""pyblitzdg-shaped front end over the C ABI.
+
+Same class, method and property names as the reference's boost::python module
+(src/pyblitzdg/pyblitzdg.cpp:59-201) for the objects the sw2d / advec1d path uses:
+``MeshManager``, ``TriangleNodesProvisioner`` (+ ``dgContext()`` -> ``DGContext2D``),
+``Nodes1DProvisioner``, ``LSERK4``, ``BCType``. As in the reference every property
+access returns a FRESH C-order ndarray (float64 / int32). Objects outside the hot
+path (quads, Gauss/cubature contexts, VTK, Poisson) are not provided.
+"""
+import numpy as np
+
+from . import _capi as C
+from ._capi import byref, c_double, c_int, c_void_p, check, lib
+
+
+class _BCType:
+    """reference: struct BCType in src/pyblitzdg/pyblitzdg.cpp:52-56"""
+    Dirichlet = 6
+    Neuman = 7
+    Wall = 3
+
+
+BCType = _BCType()
+
+
+class _LSERK4:
+    """reference: include/LSERK4.hpp:15-29, exported at src/pyblitzdg/pyblitzdg.cpp:28-50,96-99"""
+    numStages = lib.bdg_lserk4_num_stages()
+
+    @property
+    def rk4a(self):
+        return np.array([lib.bdg_lserk4_a()[i] for i in range(self.numStages)], dtype=np.float64)
+
+    @property
+    def rk4b(self):
+        return np.array([lib.bdg_lserk4_b()[i] for i in range(self.numStages)], dtype=np.float64)
+
+
+LSERK4 = _LSERK4()
+
+
+class MeshManager:
+    """reference: include/MeshManager.hpp:23-232; python names at pyblitzdg.cpp:101-112"""
+
+    def __init__(self):
+        h = c_void_p()
+        check(lib.bdg_mesh_create(byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.bdg_mesh_destroy(h)
+
+    def readMesh(self, gmshInputFile):
+        check(lib.bdg_mesh_read(self._h, str(gmshInputFile).encode()))
+
+    def buildMesh(self, EToV, Vert):
+        """EToV: (K, 3) vertex ids (any numeric dtype, as the reference accepts float64);
+        Vert: (Nv, 2|3) coordinates."""
+        e = C.as_i32(np.asarray(EToV).astype(np.int64))
+        v = C.as_f64(Vert)
+        if e.ndim != 2 or e.shape[1] != 3 or v.ndim != 2:
+            raise ValueError("buildMesh: EToV must be (K,3) and Vert (Nv,2|3)")
+        check(lib.bdg_mesh_build(self._h, C.ptr(e), e.shape[0], C.ptr(v), v.shape[0], v.shape[1]))
+
+    def buildBoxMesh(self, nx, ny, x0=-1.0, x1=1.0, y0=-1.0, y1=1.0, shuffleSeed=0):
+        """Synthetic structured box, K = 2*nx*ny CCW triangles (benchmark configurations)."""
+        check(lib.bdg_mesh_build_box(self._h, nx, ny, x0, x1, y0, y1, shuffleSeed))
+
+    def partitionMesh(self, numPartitions):
+        check(lib.bdg_mesh_partition(self._h, int(numPartitions)))
+
+    def setBCType(self, bcType):
+        b = C.as_i32(bcType).reshape(-1)
+        check(lib.bdg_mesh_set_bctype(self._h, C.ptr(b), b.size))
+
+    def _table(self, which):
+        t = C.Table()
+        check(lib.bdg_mesh_table(self._h, which, byref(t)))
+        return C.table_to_numpy(t)
+
+    numElements = property(lambda self: lib.bdg_mesh_num_elements(self._h))
+    numVerts = property(lambda self: lib.bdg_mesh_num_verts(self._h))
+    vertices = property(lambda self: self._table(C.MESH_VERTICES))
+    elements = property(lambda self: self._table(C.MESH_ELEMENTS))
+    bcType = property(lambda self: self._table(C.MESH_BCTYPE))
+    EToE = property(lambda self: self._table(C.MESH_ETOE))
+    EToF = property(lambda self: self._table(C.MESH_ETOF))
+    elementPartitionMap = property(lambda self: self._table(C.MESH_EPART))
+    vertexPartitionMap = property(lambda self: self._table(C.MESH_NPART))
+
+
+class DGContext2D:
+    """Read-only view of a TriangleNodesProvisioner's tables.
+    reference: include/DGContext2D.hpp:9-258; python names at pyblitzdg.cpp:160-187."""
+
+    _TABLES = {
+        "filter": C.TRI_FILTER, "r": C.TRI_R, "s": C.TRI_S, "x": C.TRI_X, "y": C.TRI_Y,
+        "Fscale": C.TRI_FSCALE, "Fmask": C.TRI_FMASK, "gather": C.TRI_GATHER, "scatter": C.TRI_SCATTER,
+        "J": C.TRI_J, "rx": C.TRI_RX, "ry": C.TRI_RY, "sx": C.TRI_SX, "sy": C.TRI_SY, "nx": C.TRI_NX,
+        "ny": C.TRI_NY, "Dr": C.TRI_DR, "Ds": C.TRI_DS, "Lift": C.TRI_LIFT, "vmapM": C.TRI_VMAPM,
+        "vmapP": C.TRI_VMAPP, "V": C.TRI_V, "Vinv": C.TRI_VINV,
+    }
+
+    def __init__(self, nodes):
+        self._nodes = nodes  # keeps the provisioner (and its mesh) alive
+
+    def __getattr__(self, name):
+        which = DGContext2D._TABLES.get(name)
+        if which is None:
+            raise AttributeError(name)
+        return self._nodes._table(which)
+
+    @property
+    def numLocalPoints(self):
+        return self._nodes._dims()[1]
+
+    @property
+    def numFacePoints(self):
+        return self._nodes._dims()[2]
+
+    @property
+    def numElements(self):
+        return self._nodes._dims()[3]
+
+    @property
+    def numFaces(self):
+        return 3
+
+    @property
+    def order(self):
+        return self._nodes._dims()[0]
+
+    @property
+    def BCmap(self):
+        return self._nodes._bcmap()
+
+
+class TriangleNodesProvisioner:
+    """reference: include/TriangleNodesProvisioner.hpp:32-427; python names at pyblitzdg.cpp:114-119"""
+
+    def __init__(self, NOrder, meshManager):
+        h = c_void_p()
+        check(lib.bdg_trinodes_create(int(NOrder), meshManager._h, byref(h)))
+        self._h = h
+        self._mesh = meshManager  # the C++ object borrows the mesh
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.bdg_trinodes_destroy(h)
+
+    def buildFilter(self, Nc, s):
+        check(lib.bdg_trinodes_build_filter(self._h, float(Nc), int(s)))
+
+    def buildBCHash(self, bcType):
+        b = C.as_i32(bcType).reshape(-1)
+        check(lib.bdg_trinodes_build_bchash(self._h, C.ptr(b), b.size))
+
+    def setCoordinates(self, x, y):
+        _, Np, _, K = self._dims()
+        xa, ya = C.as_f64(x, (Np, K), "x"), C.as_f64(y, (Np, K), "y")
+        check(lib.bdg_trinodes_set_coordinates(self._h, C.ptr(xa), C.ptr(ya)))
+
+    def dgContext(self):
+        return DGContext2D(self)
+
+    def _dims(self):
+        o, np_, nfp, k = c_int(), c_int(), c_int(), c_int()
+        check(lib.bdg_trinodes_dims(self._h, byref(o), byref(np_), byref(nfp), byref(k)))
+        return o.value, np_.value, nfp.value, k.value
+
+    def _table(self, which, copy=True):
+        t = C.Table()
+        check(lib.bdg_trinodes_table(self._h, which, byref(t)))
+        return C.table_to_numpy(t, copy=copy)
+
+    def _bcmap(self):
+        n = lib.bdg_trinodes_bcmap_num_tags(self._h)
+        tags = (c_int * max(n, 1))()
+        check(lib.bdg_trinodes_bcmap_tags(self._h, tags, n))
+        out = {}
+        for i in range(n):
+            p, cnt = C.POINTER(c_int)(), c_int()
+            check(lib.bdg_trinodes_bcmap_nodes(self._h, tags[i], byref(p), byref(cnt)))
+            out[int(tags[i])] = [int(p[j]) for j in range(cnt.value)]
+        return out
+
+
+class Nodes1DProvisioner:
+    """reference: include/Nodes1DProvisioner.hpp:25-302; python names at pyblitzdg.cpp:66-81"""
+
+    def __init__(self, NOrder, K, xLeft, xRight):
+        h = c_void_p()
+        check(lib.bdg_nodes1d_create(int(NOrder), int(K), float(xLeft), float(xRight), byref(h)))
+        self._h = h
+        self._order, self._K = int(NOrder), int(K)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.bdg_nodes1d_destroy(h)
+
+    def buildNodes(self):
+        check(lib.bdg_nodes1d_build_nodes(self._h))
+
+    def computeJacobian(self):
+        check(lib.bdg_nodes1d_compute_jacobian(self._h))
+
+    def _table(self, which):
+        t = C.Table()
+        check(lib.bdg_nodes1d_table(self._h, which, byref(t)))
+        return C.table_to_numpy(t)
+
+    numLocalPoints = property(lambda self: self._order + 1)
+    numElements = property(lambda self: self._K)
+    rGrid = property(lambda self: self._table(C.N1D_R))
+    xGrid = property(lambda self: self._table(C.N1D_X))
+    V = property(lambda self: self._table(C.N1D_V))
+    Dr = property(lambda self: self._table(C.N1D_DR))
+    rx = property(lambda self: self._table(C.N1D_RX))
+    J = property(lambda self: self._table(C.N1D_J))
+    Fscale = property(lambda self: self._table(C.N1D_FSCALE))
+    Fmask = property(lambda self: self._table(C.N1D_FMASK))
+    Fx = property(lambda self: self._table(C.N1D_FX))
+    Lift = property(lambda self: self._table(C.N1D_LIFT))
+    EToV = property(lambda self: self._table(C.N1D_ETOV))
+    EToE = property(lambda self: self._table(C.N1D_ETOE))
+    EToF = property(lambda self: self._table(C.N1D_ETOF))
+    vmapM = property(lambda self: self._table(C.N1D_VMAPM))
+    vmapP = property(lambda self: self._table(C.N1D_VMAPP))
+    nx = property(lambda self: self._table(C.N1D_NX))
+    mapI = property(lambda self: lib.bdg_nodes1d_map_i(self._h))
+    mapO = property(lambda self: lib.bdg_nodes1d_map_o(self._h))
+
+
+def advec1dRun(N=4, K=30, xmin=-1.0, xmax=4.0, c=0.1, CFL=0.8, finalTime=20.0):
+    """The reference's bin/advec1d (src/advec1d/main.cpp:35-122) with N, K as arguments;
+    host-only LSERK4 loop. Returns (max-norm error vs exact, number of steps)."""
+    err, steps = c_double(), c_int()
+    check(lib.bdg_advec1d_run(N, K, xmin, xmax, c, CFL, finalTime, byref(err), byref(steps)))
+    return err.value, steps.value

@@ -1,0 +1,143 @@
+"""Host-side mirror of the reference's sw2d driver vocabulary over the C ABI.
+
+``computeRHS(h, hu, hv, g, nodes)`` has the argument meaning of
+``blitzdg::sw2d::computeRHS`` (reference src/sw2d-simple/main.cpp:181, decl SW2d.hpp:15):
+(Np, K) fields in, three (Np, K) RHS arrays out. ``Sw2dSolver`` keeps the state resident
+in HBM and exposes the reference drivers' loop bodies (LSERK4 stages,
+src/advec1d/main.cpp:92-102; midpoint RK2 + filter, src/sw2d-simple/main.cpp:132-151;
+adaptive dt and blow-up check, :153-167).
+
+Everything here calls the HIP library; there is no CPU implementation behind it.
+"""
+import weakref
+
+import numpy as np
+
+from . import _capi as C
+from ._capi import byref, c_double, c_float, c_int, c_void_p, check, lib
+
+REORDER = C.BDG_SW2D_REORDER
+
+
+class Sw2dSolver:
+    """Device-resident shallow-water DG solver (one HIP device, one stream)."""
+
+    def __init__(self, nodes=None, g=9.81, device=0, flags=0, tables=None):
+        """Create from a ``pyblitzdg.TriangleNodesProvisioner`` (``nodes``) or from a dict of
+        host tables (``tables``: order, Dr, Ds, Lift, rx, sx, ry, sy, nx, ny, Fscale, vmapP, mapW and
+        optionally vmapM, Filter)."""
+        h = c_void_p()
+        if nodes is not None:
+            check(lib.bdg_sw2d_create_from_nodes(nodes._h, float(g), int(device), int(flags), byref(h)))
+            _, self.Np, self.Nfp, self.K = nodes._dims()
+            self.order = nodes._dims()[0]
+        elif tables is not None:
+            t = dict(tables)
+            order = int(t["order"])
+            rx = C.as_f64(t["rx"])
+            Np, K = rx.shape
+            nfn = 3 * (order + 1)
+            arrs = {
+                "Dr": C.as_f64(t["Dr"], (Np, Np), "Dr"), "Ds": C.as_f64(t["Ds"], (Np, Np), "Ds"),
+                "Lift": C.as_f64(t["Lift"], (Np, nfn), "Lift"),
+                "rx": rx, "sx": C.as_f64(t["sx"], (Np, K), "sx"), "ry": C.as_f64(t["ry"], (Np, K), "ry"),
+                "sy": C.as_f64(t["sy"], (Np, K), "sy"), "nx": C.as_f64(t["nx"], (nfn, K), "nx"),
+                "ny": C.as_f64(t["ny"], (nfn, K), "ny"), "Fscale": C.as_f64(t["Fscale"], (nfn, K), "Fscale"),
+                "vmapP": C.as_i32(t["vmapP"]).reshape(-1), "mapW": C.as_i32(t.get("mapW", [])).reshape(-1),
+            }
+            if arrs["vmapP"].size != nfn * K:
+                raise ValueError("vmapP must have 3*Nfp*K entries")
+            filt = C.as_f64(t["Filter"], (Np, Np), "Filter") if t.get("Filter") is not None else None
+            vmapM = C.as_i32(t["vmapM"]).reshape(-1) if t.get("vmapM") is not None else None
+            d = C.Sw2dDesc(order, K, C.ptr(arrs["Dr"]), C.ptr(arrs["Ds"]), C.ptr(arrs["Lift"]), C.ptr(filt),
+                           C.ptr(arrs["rx"]), C.ptr(arrs["sx"]), C.ptr(arrs["ry"]), C.ptr(arrs["sy"]),
+                           C.ptr(arrs["nx"]), C.ptr(arrs["ny"]), C.ptr(arrs["Fscale"]), C.ptr(vmapM),
+                           C.ptr(arrs["vmapP"]), C.ptr(arrs["mapW"]), arrs["mapW"].size, float(g), int(device),
+                           int(flags))
+            check(lib.bdg_sw2d_create(byref(d), byref(h)))
+            self.order, self.Np, self.Nfp, self.K = order, Np, order + 1, K
+        else:
+            raise ValueError("Sw2dSolver needs `nodes` or `tables`")
+        self._h = h
+        self.g = float(g)
+        self._finalizer = weakref.finalize(self, lib.bdg_sw2d_destroy, h)
+
+    def close(self):
+        self._finalizer()
+        self._h = None
+
+    # ---- state
+    def _field(self, a, name):
+        return C.as_f64(a, (self.Np, self.K), name)
+
+    def setState(self, h, hu, hv):
+        h, hu, hv = self._field(h, "h"), self._field(hu, "hu"), self._field(hv, "hv")
+        check(lib.bdg_sw2d_set_state(self._h, C.ptr(h), C.ptr(hu), C.ptr(hv)))
+
+    def getState(self):
+        out = [np.empty((self.Np, self.K)) for _ in range(3)]
+        check(lib.bdg_sw2d_get_state(self._h, *[C.ptr(o) for o in out]))
+        return tuple(out)
+
+    def setBathymetry(self, H):
+        Hh = self._field(H, "H") if H is not None else None
+        check(lib.bdg_sw2d_set_bathymetry(self._h, C.ptr(Hh)))
+
+    # ---- RHS (host in, host out)
+    def computeRHS(self, h, hu, hv, filter=False):
+        h, hu, hv = self._field(h, "h"), self._field(hu, "hu"), self._field(hv, "hv")
+        out = [np.empty((self.Np, self.K)) for _ in range(3)]
+        check(lib.bdg_sw2d_rhs(self._h, C.ptr(h), C.ptr(hu), C.ptr(hv), *[C.ptr(o) for o in out], int(bool(filter))))
+        return tuple(out)
+
+    # ---- resident time stepping
+    def stepLSERK4(self, dt, nsteps=1):
+        check(lib.bdg_sw2d_step_lserk4(self._h, float(dt), int(nsteps)))
+
+    def lserk4Stages(self, dt, nstages):
+        check(lib.bdg_sw2d_lserk4_stages(self._h, float(dt), int(nstages)))
+
+    def stepRK2(self, dt, nsteps=1, filter=True):
+        check(lib.bdg_sw2d_step_rk2(self._h, float(dt), int(nsteps), int(bool(filter))))
+
+    def computeDt(self, CFL):
+        """(dt, max|eta|); raises NumericalInstability on NaN or |eta| > 1e8."""
+        dt, em = c_double(), c_double()
+        check(lib.bdg_sw2d_compute_dt(self._h, float(CFL), byref(dt), byref(em)))
+        return dt.value, em.value
+
+    def runAdaptive(self, CFL, finalTime, t=0.0, dt=None, maxSteps=0, filter=True):
+        """The reference's while-loop body (src/sw2d-simple/main.cpp:121-171). Returns (t, dt, steps)."""
+        if dt is None:
+            dt, _ = self.computeDt(CFL)
+        tt, dd, st = c_double(t), c_double(dt), c_int()
+        check(lib.bdg_sw2d_run_adaptive(self._h, float(CFL), float(finalTime), int(maxSteps), int(bool(filter)),
+                                        byref(tt), byref(dd), byref(st)))
+        return tt.value, dd.value, st.value
+
+    def synchronize(self):
+        check(lib.bdg_sw2d_synchronize(self._h))
+
+    def timeLSERK4Stages(self, dt, nstages):
+        """Average device milliseconds per fused stage launch (HIP events on the solver's stream)."""
+        ms = c_float()
+        check(lib.bdg_sw2d_time_lserk4_stages(self._h, float(dt), int(nstages), byref(ms)))
+        return ms.value
+
+    @property
+    def deviceBytes(self):
+        return lib.bdg_sw2d_device_bytes(self._h)
+
+
+_solver_cache = weakref.WeakKeyDictionary()
+
+
+def computeRHS(h, hu, hv, g, triangleNodesProvisioner, filter=False, device=0):
+    """Drop-in for ``blitzdg::sw2d::computeRHS(h, hu, hv, g, nodes, RHS1, RHS2, RHS3)``: returns
+    (RHS1, RHS2, RHS3). The device image of the provisioner's tables is cached per provisioner."""
+    key = triangleNodesProvisioner
+    entry = _solver_cache.get(key)
+    if entry is None or entry[0] != (float(g), int(device)):
+        entry = ((float(g), int(device)), Sw2dSolver(nodes=key, g=g, device=device))
+        _solver_cache[key] = entry
+    return entry[1].computeRHS(h, hu, hv, filter=filter)

@@ -1,0 +1,219 @@
+/* blitzdg_hip.h -- C ABI of the MI355X-native blitzdg hot path.
+ *
+ * One shared library (libblitzdg_hip.so) with two groups of entry points:
+ *
+ *  (1) Host setup handles (CPU): mesh, 2-D triangle nodes provisioner, 1-D nodes
+ *      provisioner. They build exactly the tables the reference's C++ classes
+ *      build and export them as borrowed (pointer, rows, cols) views. This is the
+ *      seam the reference crosses with boost::python in src/pyblitzdg/pyblitzdg.cpp
+ *      :59-201 (MeshManager, TriangleNodesProvisioner/DGContext2D,
+ *      Nodes1DProvisioner, LSERK4); blitzdg_amd/pyblitzdg.py binds it with ctypes.
+ *
+ *  (2) The device-resident sw2d solver (HIP, gfx950): right-hand-side evaluation
+ *      and Runge-Kutta stage updates of the 2-D shallow-water nodal DG scheme.
+ *      bdg_sw2d_rhs replaces blitzdg::sw2d::computeRHS
+ *      (reference src/sw2d-simple/main.cpp:181-356, decl SW2d.hpp:15);
+ *      bdg_sw2d_step_lserk4 replaces the LSERK4 stage loop
+ *      (src/advec1d/main.cpp:92-102 with include/LSERK4.hpp:15-29);
+ *      bdg_sw2d_step_rk2 replaces the midpoint-RK2 + filter loop body
+ *      (src/sw2d-simple/main.cpp:132-151); bdg_sw2d_compute_dt replaces the
+ *      time-step/blow-up reductions (src/sw2d-simple/main.cpp:98-109,153-167).
+ *
+ * Conventions: every (rows, K) field/table is row-major fp64 with K (the element
+ * index) contiguous, as in the reference (include/Types.hpp:16-18); index tables
+ * are int32 and use the reference's column-wise node numbering n + Np*k.
+ * Every function returns 0 on success or a BDG_ERR_* code; bdg_last_error()
+ * returns a thread-local message. No exceptions cross this boundary. A handle
+ * must be used from one host thread at a time.
+ */
+#ifndef BLITZDG_HIP_H
+#define BLITZDG_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDG_OK 0
+#define BDG_ERR_ARGUMENT 1  /* null pointer, bad size, unsupported order ...   */
+#define BDG_ERR_RUNTIME 2   /* I/O or setup failure (message has the details) */
+#define BDG_ERR_HIP 3       /* a HIP call failed / no usable device            */
+#define BDG_ERR_UNSTABLE 4  /* NaN or |eta| > 1e8 detected ("A numerical instability has occurred!") */
+
+typedef struct bdg_mesh bdg_mesh;
+typedef struct bdg_trinodes bdg_trinodes;
+typedef struct bdg_nodes1d bdg_nodes1d;
+typedef struct bdg_sw2d bdg_sw2d;
+
+const char* bdg_last_error(void);
+int bdg_version(void);
+
+/* ---------------------------------------------------------------- tables */
+
+/* dtype codes of a table view */
+#define BDG_F64 0
+#define BDG_I32 1
+
+/* Borrowed view of a host table; valid until the owning handle is destroyed or rebuilt. */
+typedef struct bdg_table {
+    const void* data;
+    int rows;   /* 1-D tables: rows = length, cols = 1 */
+    int cols;
+    int dtype;  /* BDG_F64 or BDG_I32 */
+} bdg_table;
+
+/* ---------------------------------------------------------------- MeshManager
+ * reference: include/MeshManager.hpp:23-232, src/MeshManager.cpp */
+enum {
+    BDG_MESH_VERTICES = 0, /* (Nv, 3) f64 */
+    BDG_MESH_ELEMENTS = 1, /* (K, 3) i32, CCW */
+    BDG_MESH_ETOE = 2,     /* (K, 3) i32 */
+    BDG_MESH_ETOF = 3,     /* (K, 3) i32 */
+    BDG_MESH_BCTYPE = 4,   /* (K, 3) i32: 0 interior, 3 wall ... */
+    BDG_MESH_EPART = 5,    /* (K) i32, after bdg_mesh_partition */
+    BDG_MESH_NPART = 6     /* (Nv) i32, after bdg_mesh_partition */
+};
+int bdg_mesh_create(bdg_mesh** out);
+void bdg_mesh_destroy(bdg_mesh* mesh);
+int bdg_mesh_read(bdg_mesh* mesh, const char* gmsh_path);                 /* readMesh   */
+int bdg_mesh_build(bdg_mesh* mesh, const int* etov, int num_elements,     /* buildMesh  */
+                   const double* vert, int num_verts, int dim);
+int bdg_mesh_build_box(bdg_mesh* mesh, int nx, int ny, double x0, double x1, double y0, double y1,
+                       unsigned long long shuffle_seed);                  /* synthetic box, K = 2*nx*ny */
+int bdg_mesh_set_bctype(bdg_mesh* mesh, const int* bctype, int n);        /* setBCType  */
+int bdg_mesh_partition(bdg_mesh* mesh, int num_partitions);               /* partitionMesh */
+int bdg_mesh_num_elements(const bdg_mesh* mesh);
+int bdg_mesh_num_verts(const bdg_mesh* mesh);
+int bdg_mesh_table(const bdg_mesh* mesh, int which, bdg_table* out);
+
+/* ---------------------------------------------------------------- TriangleNodesProvisioner / DGContext2D
+ * reference: include/TriangleNodesProvisioner.hpp:32-427, include/DGContext2D.hpp:9-258 */
+enum {
+    BDG_TRI_R = 0, BDG_TRI_S, BDG_TRI_X, BDG_TRI_Y, BDG_TRI_V, BDG_TRI_VINV, BDG_TRI_DR, BDG_TRI_DS,
+    BDG_TRI_DRW, BDG_TRI_DSW, BDG_TRI_LIFT, BDG_TRI_FILTER, BDG_TRI_J, BDG_TRI_RX, BDG_TRI_RY, BDG_TRI_SX,
+    BDG_TRI_SY, BDG_TRI_NX, BDG_TRI_NY, BDG_TRI_FSCALE, BDG_TRI_FMASK, BDG_TRI_FX, BDG_TRI_FY,
+    BDG_TRI_VMAPM, BDG_TRI_VMAPP, BDG_TRI_MAPP, BDG_TRI_VMAPB, BDG_TRI_MAPB, BDG_TRI_GATHER, BDG_TRI_SCATTER
+};
+int bdg_trinodes_create(int order, const bdg_mesh* mesh, bdg_trinodes** out); /* mesh must outlive it */
+void bdg_trinodes_destroy(bdg_trinodes* nodes);
+int bdg_trinodes_build_filter(bdg_trinodes* nodes, double Nc, int s);
+int bdg_trinodes_build_bchash(bdg_trinodes* nodes, const int* bctype, int n); /* appends, as the reference */
+int bdg_trinodes_set_coordinates(bdg_trinodes* nodes, const double* x, const double* y);
+int bdg_trinodes_dims(const bdg_trinodes* nodes, int* order, int* np, int* nfp, int* num_elements);
+int bdg_trinodes_table(const bdg_trinodes* nodes, int which, bdg_table* out);
+/* BCmap: number of tags; tag list; node list of one tag (borrowed). */
+int bdg_trinodes_bcmap_num_tags(const bdg_trinodes* nodes);
+int bdg_trinodes_bcmap_tags(const bdg_trinodes* nodes, int* tags, int capacity);
+int bdg_trinodes_bcmap_nodes(const bdg_trinodes* nodes, int tag, const int** nodes_out, int* count);
+
+/* ---------------------------------------------------------------- Nodes1DProvisioner
+ * reference: include/Nodes1DProvisioner.hpp:25-302 */
+enum {
+    BDG_N1D_R = 0, BDG_N1D_X, BDG_N1D_V, BDG_N1D_VINV, BDG_N1D_DR, BDG_N1D_LIFT, BDG_N1D_J, BDG_N1D_RX,
+    BDG_N1D_NX, BDG_N1D_FMASK, BDG_N1D_FX, BDG_N1D_FSCALE, BDG_N1D_ETOV, BDG_N1D_ETOE, BDG_N1D_ETOF,
+    BDG_N1D_VMAPM, BDG_N1D_VMAPP
+};
+int bdg_nodes1d_create(int order, int num_elements, double xmin, double xmax, bdg_nodes1d** out);
+void bdg_nodes1d_destroy(bdg_nodes1d* nodes);
+int bdg_nodes1d_build_nodes(bdg_nodes1d* nodes);
+int bdg_nodes1d_compute_jacobian(bdg_nodes1d* nodes);
+int bdg_nodes1d_map_i(const bdg_nodes1d* nodes);
+int bdg_nodes1d_map_o(const bdg_nodes1d* nodes);
+int bdg_nodes1d_table(const bdg_nodes1d* nodes, int which, bdg_table* out);
+
+/* LSERK4 coefficients (reference include/LSERK4.hpp:15-29); 5 entries each. */
+int bdg_lserk4_num_stages(void);
+const double* bdg_lserk4_a(void);
+const double* bdg_lserk4_b(void);
+
+/* advec1d: CPU plumbing config (reference src/advec1d/main.cpp:35-122). Runs the
+ * LSERK4 loop on the host to t >= final_time and returns the max-norm error
+ * against the translated Gaussian. No GPU involved. */
+int bdg_advec1d_run(int order, int num_elements, double xmin, double xmax, double c, double cfl,
+                    double final_time, double* max_error, int* num_steps);
+
+/* ---------------------------------------------------------------- sw2d device solver */
+
+/* Host tables a solver is created from (all borrowed for the duration of the call). */
+typedef struct bdg_sw2d_desc {
+    int order;          /* N: 1..BDG_SW2D_MAX_ORDER                                   */
+    int num_elements;   /* K                                                          */
+    const double* Dr;   /* (Np, Np)                                                   */
+    const double* Ds;   /* (Np, Np)                                                   */
+    const double* Lift; /* (Np, 3*Nfp)                                                */
+    const double* Filter; /* (Np, Np) or NULL (no filter available)                   */
+    const double* rx; const double* sx; const double* ry; const double* sy; /* (Np, K) */
+    const double* nx; const double* ny; const double* Fscale;               /* (3*Nfp, K) */
+    const int* vmapM;   /* (3*Nfp*K) volume node of each face node, n + Np*k; may be NULL */
+    const int* vmapP;   /* (3*Nfp*K) neighbour node of each face node                 */
+    const int* mapW;    /* BCmap[3]: flat face-node indices of reflective-wall nodes  */
+    int num_wall;
+    double g;           /* gravitational acceleration                                 */
+    int device;         /* HIP device ordinal                                         */
+    int flags;          /* BDG_SW2D_* bits                                            */
+} bdg_sw2d_desc;
+
+#define BDG_SW2D_MAX_ORDER 6
+#define BDG_SW2D_REORDER 1u /* renumber elements internally for gather locality (results are
+                               returned in the caller's numbering either way)         */
+
+int bdg_sw2d_create(const bdg_sw2d_desc* desc, bdg_sw2d** out);
+/* Convenience: take every table from a nodes provisioner (wall nodes = BCmap[3]). */
+int bdg_sw2d_create_from_nodes(const bdg_trinodes* nodes, double g, int device, int flags, bdg_sw2d** out);
+void bdg_sw2d_destroy(bdg_sw2d* s);
+
+/* State I/O: host (Np, K) row-major arrays in the caller's element numbering. */
+int bdg_sw2d_set_state(bdg_sw2d* s, const double* h, const double* hu, const double* hv);
+int bdg_sw2d_get_state(bdg_sw2d* s, double* h, double* hu, double* hv);
+/* Still-water depth H used only by the eta = h - H blow-up check; default: none (check h). */
+int bdg_sw2d_set_bathymetry(bdg_sw2d* s, const double* H);
+
+/* Drop-in for computeRHS: host fields in, host RHS out (upload, one kernel, download).
+ * Does not disturb the resident state. filter != 0 applies Filter to the result. */
+int bdg_sw2d_rhs(bdg_sw2d* s, const double* h, const double* hu, const double* hv, double* rhs1,
+                 double* rhs2, double* rhs3, int filter);
+
+/* Resident time stepping (state stays in HBM). */
+int bdg_sw2d_step_lserk4(bdg_sw2d* s, double dt, int num_steps);          /* 5 fused stages per step */
+int bdg_sw2d_lserk4_stages(bdg_sw2d* s, double dt, int num_stages);       /* stage i = count % 5      */
+int bdg_sw2d_step_rk2(bdg_sw2d* s, double dt, int num_steps, int filter); /* midpoint RK2            */
+/* dt = CFL / ((N+1)^2 * 0.5 * max_i |Fscale_i| * (|u|+sqrt(g h))[vmapM_i]); also returns
+ * max|eta| (or max|h|) and BDG_ERR_UNSTABLE on NaN / > 1e8. */
+int bdg_sw2d_compute_dt(bdg_sw2d* s, double cfl, double* dt, double* eta_max);
+/* Reference driver loop body (src/sw2d-simple/main.cpp:121-171): RK2 step with
+ * filter, blow-up check, adaptive dt; runs until t >= final_time or max_steps. */
+int bdg_sw2d_run_adaptive(bdg_sw2d* s, double cfl, double final_time, int max_steps, int filter,
+                          double* t_inout, double* dt_inout, int* steps_done);
+
+/* ---- multi-GPU: element partition with a ghost layer (no reference analogue; the reference
+ * only computes METIS partition vectors, src/MeshManager.cpp:491-544, and never uses them).
+ * The solver is created on a LOCAL mesh whose elements are ordered
+ *   [ interior | partition-boundary | ghost ]            (ghost = owned by another rank)
+ * Only [0, num_owned) are updated; ghost state is refreshed each stage by the caller:
+ *   pack (device buffer of num_send*3*Np doubles, element-major) -> exchange (RCCL, caller's
+ *   job) -> unpack into the ghost slots, while the interior elements are already computing. */
+int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const int* send_elements,
+                           int num_send);
+int bdg_sw2d_halo_doubles_per_element(const bdg_sw2d* s);
+int bdg_sw2d_halo_pack(bdg_sw2d* s, void* send_buffer_device);
+int bdg_sw2d_halo_unpack(bdg_sw2d* s, const void* recv_buffer_device);
+/* One LSERK4 stage over part of the owned elements: 0 = interior only (does not advance the
+ * stage), 1 = partition-boundary elements then advance, 2 = all owned elements then advance. */
+int bdg_sw2d_lserk4_stage_part(bdg_sw2d* s, double dt, int part);
+/* RHS of the resident state (owned elements valid; ghosts must be current) to host arrays. */
+int bdg_sw2d_rhs_resident(bdg_sw2d* s, double* rhs1, double* rhs2, double* rhs3);
+
+int bdg_sw2d_synchronize(bdg_sw2d* s);
+/* Runs num_stages LSERK4 stages bracketed by HIP events on the solver's own stream and
+ * returns the average device time per stage-kernel launch in milliseconds. */
+int bdg_sw2d_time_lserk4_stages(bdg_sw2d* s, double dt, int num_stages, float* ms_per_launch);
+/* Bytes of HBM the solver holds; algorithmic bytes per element per fused stage. */
+size_t bdg_sw2d_device_bytes(const bdg_sw2d* s);
+/* The raw stream (hipStream_t) launches are issued on, for callers that interleave their own work. */
+void* bdg_sw2d_stream(bdg_sw2d* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLITZDG_HIP_H */

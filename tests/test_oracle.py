@@ -1,0 +1,149 @@
+"""Pins the CPU oracle (oracle/oracle_sw2d.c) -- the checker of the HIP path.
+
+ * against the RHS computed by the REFERENCE's own NumPy implementation
+   (swhelpers/rhs.py:178-311), committed as tests/golden/sw2d_rhs_*.npz by
+   tests/golden/make_golden.py;
+ * through analytic properties for the pieces that have no importable reference
+   (steppers, dt, advec1d): lake at rest, mass conservation, LSERK4 order, exactness.
+Tolerance: relative max-norm 1e-12 against the reference fixtures (measured ~3e-14; the two
+differ only in rounding: (hu*hu)/h vs hu*(hu/h), FMA-free summation in both).
+"""
+import numpy as np
+import pytest
+
+import blitzdg_amd.pyblitzdg as dg
+from conftest import load_case, oracle_from, relmax, seeded_fields, tables_from_nodes
+from oracle import advec1d_rhs, advec1d_steps, lserk4_coefficients
+
+CASES = ["coarse_box_N1", "coarse_box_N2", "coarse_box_N3", "coarse_box_N4", "coarse_box_N5", "coarse_box_N6",
+         "box2x2_N8", "box6x5_shuffled_N4"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_matches_reference_rhs(case):
+    d = load_case(case)
+    o = oracle_from(d, g=float(d["g"]))
+    r = o.rhs(d["h"], d["hu"], d["hv"])
+    scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
+    for i in range(3):
+        assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < 1e-12
+
+
+def test_oracle_threads_do_not_change_results():
+    d = load_case("coarse_box_N4")
+    a = oracle_from(d, threads=1).rhs(d["h"], d["hu"], d["hv"])
+    b = oracle_from(d, threads=4).rhs(d["h"], d["hu"], d["hv"])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_lake_at_rest_rhs_vanishes():
+    d = load_case("coarse_box_N3")
+    o = oracle_from(d)
+    h = np.full_like(d["h"], 10.0)
+    z = np.zeros_like(h)
+    r = o.rhs(h, z, z)
+    # momentum equations carry g h^2/2 ~ 490: round-off of Dr*const, relative to that
+    assert max(np.abs(x).max() for x in r) < 1e-10
+
+
+def test_filtered_rhs_is_filter_times_rhs():
+    d = load_case("coarse_box_N4")
+    o = oracle_from(d)
+    r = o.rhs(d["h"], d["hu"], d["hv"])
+    rf = o.rhs(d["h"], d["hu"], d["hv"], filter=True)
+    for a, b in zip(r, rf):
+        assert relmax(d["Filter"] @ a, b) < 1e-14
+
+
+
+
+def test_mass_is_conserved_by_both_steppers(coarse_mesh):
+    nodes = dg.TriangleNodesProvisioner(3, coarse_mesh)
+    nodes.buildFilter(0.9 * 3, 3)
+    t = tables_from_nodes(nodes)
+    ctx = nodes.dgContext()
+    w = np.linalg.inv(ctx.V @ ctx.V.T) @ np.ones(10)  # exact for degree <= N integrands
+    J = ctx.J
+    o = oracle_from(t)
+    h, hu, hv = seeded_fields(t["x"], t["y"])
+    mass0 = (w[:, None] * J * h).sum()
+    dt = 0.5 * o.dt(h, hu, hv, 0.65, 3)
+    h1, _, _ = o.step_lserk4(h, hu, hv, dt, 3)
+    h2, _, _ = o.step_rk2(h, hu, hv, dt, 3, filter=True)
+    assert abs((w[:, None] * J * h1).sum() - mass0) / mass0 < 1e-13
+    assert abs((w[:, None] * J * h2).sum() - mass0) / mass0 < 1e-13
+    assert np.abs(h1 - h).max() > 1e-4  # the state did move
+
+
+def test_lserk4_coefficients_satisfy_order_conditions():
+    """Convert the 2N-storage (a, b) pairs to Butcher form and check orders 1-4
+    (include/LSERK4.hpp:15-29 are Carpenter & Kennedy's 5-stage scheme)."""
+    a, b = lserk4_coefficients()
+    s = 5
+    # res_i = a_i res_{i-1} + dt k_i; u += b_i res_i  =>  weight of k_j in stage increment i
+    W = np.zeros((s, s))
+    for i in range(s):
+        for j in range(i + 1):
+            W[i, j] = b[i] * np.prod(a[j + 1:i + 1])
+    Bw = W.sum(axis=0)                    # final weights
+    A = np.zeros((s, s))
+    for i in range(s):
+        A[i, :i] = W[:i, :i].sum(axis=0)  # u at stage i = u0 + dt sum_j A_ij k_j
+    c = A.sum(axis=1)
+    assert abs(Bw.sum() - 1) < 1e-14
+    assert abs(Bw @ c - 1 / 2) < 1e-14
+    assert abs(Bw @ c ** 2 - 1 / 3) < 1e-14 and abs(Bw @ (A @ c) - 1 / 6) < 1e-14
+    assert abs(Bw @ c ** 3 - 1 / 4) < 1e-13 and abs((Bw * c) @ (A @ c) - 1 / 8) < 1e-13
+    assert abs(Bw @ (A @ c ** 2) - 1 / 12) < 1e-13 and abs(Bw @ (A @ (A @ c)) - 1 / 24) < 1e-13
+
+
+def test_lserk4_temporal_order_on_sw2d(coarse_mesh):
+    nodes = dg.TriangleNodesProvisioner(2, coarse_mesh)
+    t = tables_from_nodes(nodes)
+    o = oracle_from(t)
+    h, hu, hv = seeded_fields(t["x"], t["y"])
+    T = 0.02
+    ref = o.step_lserk4(h, hu, hv, T / 64, 64)
+    errs = []
+    for n in (2, 4, 8):
+        cur = o.step_lserk4(h, hu, hv, T / n, n)
+        errs.append(max(np.abs(a - b).max() for a, b in zip(cur, ref)))
+    rates = [np.log2(errs[i] / errs[i + 1]) for i in range(2)]
+    assert min(rates) > 3.5, (errs, rates)
+
+
+def test_dt_formula(coarse_mesh):
+    nodes = dg.TriangleNodesProvisioner(3, coarse_mesh)
+    t = tables_from_nodes(nodes)
+    o = oracle_from(t)
+    h, hu, hv = seeded_fields(t["x"], t["y"])
+    fm, em = o.fsc_eta_max(h, hu, hv, H=np.full_like(h, 10.0))
+    spd = np.sqrt((hu / h) ** 2 + (hv / h) ** 2) + np.sqrt(9.81 * h)
+    expect = (np.abs(t["Fscale"].flatten("F")) * spd.flatten("F")[t["vmapM"]]).max()
+    assert fm == expect
+    assert em == np.abs(h - 10.0).max()
+    hbad = h.copy()
+    hbad[3, 7] = np.nan
+    fm, em = o.fsc_eta_max(hbad, hu, hv)
+    assert np.isnan(fm) and np.isnan(em)
+
+
+def test_advec1d_oracle_matches_host_plumbing_and_converges():
+    errs = []
+    for K in (10, 20):
+        n = dg.Nodes1DProvisioner(4, K, -1.0, 4.0)
+        n.buildNodes()
+        n.computeJacobian()
+        x = n.xGrid
+        u0 = np.exp(-10 * (x - 1.5) ** 2)  # centred: no inflow clipping
+        c = 0.1
+        dt = 0.8 * (x[1, 0] - x[0, 0]) / c
+        args = (n.Dr, n.Lift, n.rx, n.Fscale, n.nx, n.vmapM, n.vmapP, n.mapI, n.mapO, c)
+        rhs = advec1d_rhs(*args, u0)
+        # interior: -c du/dx of the interpolant plus the upwind jump (tiny for smooth data)
+        assert np.abs(rhs + c * (-20 * (x - 1.5) * u0)).max() < (0.3 if K == 10 else 0.03)
+        nsteps = int(round(2.0 / dt))
+        u = advec1d_steps(*args, dt, nsteps, u0)
+        errs.append(np.abs(u - np.exp(-10 * (x - 1.5 - c * dt * nsteps) ** 2)).max())
+    assert errs[0] / errs[1] > 8, errs
