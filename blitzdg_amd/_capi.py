@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libblitzdg_hip.so")
 BDG_OK, BDG_ERR_ARGUMENT, BDG_ERR_RUNTIME, BDG_ERR_HIP, BDG_ERR_UNSTABLE = 0, 1, 2, 3, 4
 BDG_F64, BDG_I32 = 0, 1
 BDG_SW2D_REORDER = 1
+BDG_SW2D_NODAL_GEOMETRY = 2
 
 # enum values, in header order
 (MESH_VERTICES, MESH_ELEMENTS, MESH_ETOE, MESH_ETOF, MESH_BCTYPE, MESH_EPART, MESH_NPART) = range(7)
@@ -118,6 +119,7 @@ _SIGNATURES = {
     "bdg_sw2d_rhs_resident": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_synchronize": (c_int, [_P]),
     "bdg_sw2d_time_lserk4_stages": (c_int, [_P, c_double, c_int, POINTER(c_float)]),
+    "bdg_sw2d_uses_affine_geometry": (c_int, [_P]),
     "bdg_sw2d_device_bytes": (c_size_t, [_P]),
     "bdg_sw2d_stream": (c_void_p, [_P]),
 }

@@ -157,6 +157,8 @@ struct bdg_sw2d {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t bytes = 0;
     DevBuf<double> qA, qB, res, aux, geo, fgeo, ops, Hbuf, stage, partials, red2;
+    DevBuf<double> ageo, opsAffine, opsAffineFiltered; // affine-geometry fast path
+    bool affine = false;
     DevBuf<int> vmapP, perm, istage, sendSlots;
     int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
     double* qcur = nullptr;  // current state
@@ -200,6 +202,8 @@ struct bdg_sw2d {
         p.fgeo = fgeo.p;
         p.vmapP = vmapP.p;
         p.ops = ops.p;
+        p.ageo = ageo.p;
+        p.opsAffine = opsAffine.p;
         p.ld = ld;
         p.kbegin = 0;
         p.kend = numOwned;
@@ -207,12 +211,23 @@ struct bdg_sw2d {
         return p;
     }
 
+    // One fused pass. The affine path takes the filter through pre-multiplied operators.
+    void launchStage(int mode, bool filter, bdg_dev::StageParams& p, const char* what) {
+        if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
+        if (affine) {
+            p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
+            hipCheck(kt->stageAffine(mode, p, stream), what);
+        } else {
+            hipCheck(kt->stage(mode, filter, p, stream), what);
+        }
+    }
+
     void launchRhs(const double* qin, double* out, bool filter) {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
         bdg_dev::StageParams p = baseParams();
         p.qin = qin;
         p.rhs = out;
-        hipCheck(kt->stage(bdg_dev::MODE_RHS, filter, p, stream), "sw2d_stage_kernel<RHS>");
+        launchStage(bdg_dev::MODE_RHS, filter, p, "sw2d stage kernel <RHS>");
     }
 
     // part: 0 = interior elements only (no ghost dependency; state not advanced),
@@ -228,7 +243,7 @@ struct bdg_sw2d {
         p.ca = blitzdg::LSERK4::rk4a[s];
         p.cb = blitzdg::LSERK4::rk4b[s];
         p.cc = dtStage;
-        hipCheck(kt->stage(bdg_dev::MODE_LSERK, false, p, stream), "sw2d_stage_kernel<LSERK>");
+        launchStage(bdg_dev::MODE_LSERK, false, p, "sw2d stage kernel <LSERK>");
         if (part == 0) return;
         std::swap(qcur, qalt);
         ++stageCount;
@@ -241,10 +256,10 @@ struct bdg_sw2d {
         bdg_dev::StageParams p = baseParams();
         p.qin = qcur; p.qbase = qcur; p.qout = aux.p;
         p.ca = 1.0; p.cb = 0.0; p.cc = 0.5 * dt;
-        hipCheck(kt->stage(bdg_dev::MODE_COMBINE, filter, p, stream), "sw2d_stage_kernel<COMBINE>");
+        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
         p.ca = 1.0; p.cb = 0.0; p.cc = dt;
-        hipCheck(kt->stage(bdg_dev::MODE_COMBINE, filter, p, stream), "sw2d_stage_kernel<COMBINE>");
+        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         std::swap(qcur, qalt);
     }
 
@@ -287,6 +302,58 @@ std::vector<int> bfsOrder(const int* vmapP, int K, int Np, int Nfp) {
         }
     }
     return perm;
+}
+
+// True when the metric terms are constant per element and the face terms constant per
+// face (straight-sided elements), to round-off: then one value per element/face suffices.
+bool geometryIsAffine(const bdg_sw2d_desc& d, int Np, int Nfp, int K) {
+    const double tol = 1e-11;
+    bool ok = true;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+    for (int k = 0; k < K; ++k) {
+        const double scale = std::fabs(d.rx[k]) + std::fabs(d.sx[k]) + std::fabs(d.ry[k]) + std::fabs(d.sy[k]);
+        for (int n = 1; n < Np; ++n) {
+            const size_t o = static_cast<size_t>(n) * K + k;
+            if (std::fabs(d.rx[o] - d.rx[k]) > tol * scale || std::fabs(d.sx[o] - d.sx[k]) > tol * scale ||
+                std::fabs(d.ry[o] - d.ry[k]) > tol * scale || std::fabs(d.sy[o] - d.sy[k]) > tol * scale)
+                ok = false;
+        }
+        for (int f = 0; f < 3; ++f) {
+            const size_t o0 = static_cast<size_t>(f) * Nfp * K + k;
+            for (int n = 1; n < Nfp; ++n) {
+                const size_t o = o0 + static_cast<size_t>(n) * K;
+                if (std::fabs(d.nx[o] - d.nx[o0]) > tol || std::fabs(d.ny[o] - d.ny[o0]) > tol ||
+                    std::fabs(d.Fscale[o] - d.Fscale[o0]) > tol * std::fabs(d.Fscale[o0]))
+                    ok = false;
+            }
+        }
+    }
+    return ok;
+}
+
+// C = A (n x n) * B (n x c), row-major.
+std::vector<double> matmulHost(const double* A, const double* B, int n, int c) {
+    std::vector<double> C(static_cast<size_t>(n) * c, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < c; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += A[i * n + k] * B[k * c + j];
+            C[static_cast<size_t>(i) * c + j] = s;
+        }
+    return C;
+}
+
+// AffineOps<N> image: [m][i]{Dr[i][m], Ds[i][m]} then [j][i] Lift[i][j].
+std::vector<double> affineOpsImage(const double* Dr, const double* Ds, const double* Lift, int Np, int NFN) {
+    std::vector<double> img(static_cast<size_t>(2) * Np * Np + static_cast<size_t>(NFN) * Np);
+    for (int m = 0; m < Np; ++m)
+        for (int i = 0; i < Np; ++i) {
+            img[2 * (static_cast<size_t>(m) * Np + i)] = Dr[i * Np + m];
+            img[2 * (static_cast<size_t>(m) * Np + i) + 1] = Ds[i * Np + m];
+        }
+    for (int j = 0; j < NFN; ++j)
+        for (int i = 0; i < Np; ++i) img[static_cast<size_t>(2) * Np * Np + static_cast<size_t>(j) * Np + i] = Lift[i * NFN + j];
+    return img;
 }
 
 bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
@@ -389,6 +456,36 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->uploadRows(d.nx, s->fgeo.p, NFN);
     s->uploadRows(d.ny, s->fgeo.p + fpl, NFN);
     s->uploadRows(d.Fscale, s->fgeo.p + 2 * fpl, NFN);
+
+    // ---- affine fast path: one metric value per element, one normal/scale per face
+    s->affine = !(d.flags & BDG_SW2D_NODAL_GEOMETRY) && geometryIsAffine(d, Np, Nfp, K);
+    if (s->affine) {
+        s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);
+        hipCheck(hipMemsetAsync(s->ageo.p, 0, s->ageo.n * sizeof(double), s->stream), "hipMemset");
+        s->uploadRows(d.rx, s->ageo.p, 1);           // row 0 of each (Np, K) table
+        s->uploadRows(d.sx, s->ageo.p + ld, 1);
+        s->uploadRows(d.ry, s->ageo.p + 2 * ld, 1);
+        s->uploadRows(d.sy, s->ageo.p + 3 * ld, 1);
+        for (int f = 0; f < 3; ++f) {                 // first node of each face
+            const size_t row = static_cast<size_t>(f) * Nfp * K;
+            s->uploadRows(d.nx + row, s->ageo.p + (4 + f) * ld, 1);
+            s->uploadRows(d.ny + row, s->ageo.p + (7 + f) * ld, 1);
+            s->uploadRows(d.Fscale + row, s->ageo.p + (10 + f) * ld, 1);
+        }
+        const std::vector<double> plain = affineOpsImage(d.Dr, d.Ds, d.Lift, Np, NFN);
+        s->opsAffine.alloc(plain.size(), s->bytes);
+        hipCheck(hipMemcpy(s->opsAffine.p, plain.data(), plain.size() * sizeof(double), hipMemcpyHostToDevice),
+                 "affine ops upload");
+        if (d.Filter) {
+            // Filter * (Dr, Ds, Lift): the filtered RHS of an affine element is linear in these.
+            const std::vector<double> FDr = matmulHost(d.Filter, d.Dr, Np, Np), FDs = matmulHost(d.Filter, d.Ds, Np, Np),
+                                      FL = matmulHost(d.Filter, d.Lift, Np, NFN);
+            const std::vector<double> filt = affineOpsImage(FDr.data(), FDs.data(), FL.data(), Np, NFN);
+            s->opsAffineFiltered.alloc(filt.size(), s->bytes);
+            hipCheck(hipMemcpy(s->opsAffineFiltered.p, filt.data(), filt.size() * sizeof(double),
+                               hipMemcpyHostToDevice), "filtered affine ops upload");
+        }
+    }
 
     // ---- gather offsets: reference numbering (n' + Np*k') -> n'*ld + slot(k'), as (NFN, K) rows;
     //      wall nodes are stored as -(offset+1).
@@ -688,6 +785,8 @@ int bdg_sw2d_rhs_resident(bdg_sw2d* s, double* r1, double* r2, double* r3) {
         s->downloadRows(s->aux.p + 2 * pl, r3, s->Np);
     });
 }
+
+int bdg_sw2d_uses_affine_geometry(const bdg_sw2d* s) { return s ? (s->affine ? 1 : 0) : -1; }
 
 size_t bdg_sw2d_device_bytes(const bdg_sw2d* s) { return s ? s->bytes : 0; }
 void* bdg_sw2d_stream(bdg_sw2d* s) { return s ? static_cast<void*>(s->stream) : nullptr; }

@@ -63,6 +63,8 @@ struct StageParams {
     const double* fgeo;  // nx, ny, Fscale: 3 planes of NFN*ld
     const int* vmapP;    // NFN*ld gather offsets n'*ld + k'; wall nodes stored as -(offset+1)
     const double* ops;   // global image of the LDS block (Elem<N>::LDS_DOUBLES doubles)
+    const double* ageo;  // affine path: 13 planes of ld: rx, sx, ry, sy, nx[3], ny[3], Fscale[3]
+    const double* opsAffine; // affine path: AffineOps<N> image (plain or pre-filtered operators)
     long long ld;        // padded element count (multiple of 64)
     int kbegin, kend;    // element slots [kbegin, kend) this launch updates
     double g;

@@ -2,6 +2,7 @@
 // translation unit (sw2d_order.hip with -DBDG_ORDER=N) so the fully unrolled
 // kernels build in parallel; the solver picks the table at run time.
 #pragma once
+#include "sw2d_affine_kernel.hpp"
 #include "sw2d_kernels.hpp"
 
 namespace bdg_dev {
@@ -10,6 +11,9 @@ struct KernelTable {
     int order, Np, Nfp, ldsDoubles;
     // mode: StageMode; launches one fused RHS(+stage update) pass over K elements.
     hipError_t (*stage)(int mode, bool filter, const StageParams& p, hipStream_t stream);
+    // affine-geometry fast path (no FILTER template: the filter is folded into the operators)
+    int affineOpsDoubles;
+    hipError_t (*stageAffine)(int mode, const StageParams& p, hipStream_t stream);
     // per-block partial maxima (2 doubles per block of 256 elements)
     hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
                      double* partials, hipStream_t stream);

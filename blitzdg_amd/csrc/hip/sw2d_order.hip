@@ -29,6 +29,23 @@ hipError_t stage(int mode, bool filter, const StageParams& p, hipStream_t stream
     }
 }
 
+template <int MODE>
+hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t stageAffine(int mode, const StageParams& p, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchAffine<MODE_RHS>(p, stream);
+    case MODE_LSERK: return launchAffine<MODE_LSERK>(p, stream);
+    case MODE_COMBINE: return launchAffine<MODE_COMBINE>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t dt(const double* q, const double* fscale, const double* H, long long ld, int K, double g, double* partials,
               hipStream_t stream) {
     const unsigned grid = static_cast<unsigned>((K + kBlock - 1) / kBlock);
@@ -45,7 +62,8 @@ int fmaskOf(int f, int n) { return Elem<kN>::fmask(f, n); }
 // A host function (not a namespace-scope constant, which hipcc would also emit for
 // the device and then fail to resolve the host function pointers in).
 const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
-    static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, Elem<kN>::LDS_DOUBLES, &stage, &dt, &fmaskOf};
+    static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, Elem<kN>::LDS_DOUBLES, &stage,
+                                      AffineOps<kN>::DOUBLES, &stageAffine, &dt, &fmaskOf};
     return &table;
 }
 

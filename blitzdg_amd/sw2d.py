@@ -17,6 +17,7 @@ from . import _capi as C
 from ._capi import byref, c_double, c_float, c_int, c_void_p, check, lib
 
 REORDER = C.BDG_SW2D_REORDER
+NODAL_GEOMETRY = C.BDG_SW2D_NODAL_GEOMETRY
 
 
 class Sw2dSolver:
@@ -123,6 +124,10 @@ class Sw2dSolver:
         ms = c_float()
         check(lib.bdg_sw2d_time_lserk4_stages(self._h, float(dt), int(nstages), byref(ms)))
         return ms.value
+
+    @property
+    def usesAffineGeometry(self):
+        return bool(lib.bdg_sw2d_uses_affine_geometry(self._h))
 
     @property
     def deviceBytes(self):

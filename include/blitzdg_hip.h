@@ -157,6 +157,10 @@ typedef struct bdg_sw2d_desc {
 #define BDG_SW2D_MAX_ORDER 6
 #define BDG_SW2D_REORDER 1u /* renumber elements internally for gather locality (results are
                                returned in the caller's numbering either way)         */
+#define BDG_SW2D_NODAL_GEOMETRY 2u /* always read rx..sy, nx, ny, Fscale per node (general path).
+                               Default: if they are constant per element / per face to round-off
+                               (straight-sided elements: everything the reference's provisioner
+                               builds), one value per element / face is kept instead.      */
 
 int bdg_sw2d_create(const bdg_sw2d_desc* desc, bdg_sw2d** out);
 /* Convenience: take every table from a nodes provisioner (wall nodes = BCmap[3]). */
@@ -209,6 +213,8 @@ int bdg_sw2d_synchronize(bdg_sw2d* s);
  * returns the average device time per stage-kernel launch in milliseconds. */
 int bdg_sw2d_time_lserk4_stages(bdg_sw2d* s, double dt, int num_stages, float* ms_per_launch);
 /* Bytes of HBM the solver holds; algorithmic bytes per element per fused stage. */
+/* 1 if the solver runs the affine-geometry kernels, 0 for the per-node-geometry kernels. */
+int bdg_sw2d_uses_affine_geometry(const bdg_sw2d* s);
 size_t bdg_sw2d_device_bytes(const bdg_sw2d* s);
 /* The raw stream (hipStream_t) launches are issued on, for callers that interleave their own work. */
 void* bdg_sw2d_stream(bdg_sw2d* s);
