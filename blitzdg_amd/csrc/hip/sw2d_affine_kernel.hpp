@@ -84,27 +84,23 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
 
     __builtin_amdgcn_sched_barrier(0);
     const double g = p.g, halfg = 0.5 * p.g;
-    double R1[Np], R2[Np], R3[Np], rh[Np], spd[Np];
+    double R1[Np], R2[Np], R3[Np];
 #pragma unroll
     for (int i = 0; i < Np; ++i) R1[i] = R2[i] = R3[i] = 0.0;
-
-    // ---- per-node reciprocal depth and wave speed (used by both terms)
-#pragma unroll
-    for (int m = 0; m < Np; ++m) {
-        rh[m] = 1.0 / h[m];
-        const double u = hu[m] * rh[m], v = hv[m] * rh[m];
-        spd[m] = sqrt(u * u + v * v) + sqrt(g * h[m]);
-    }
 
     // ---- surface term, face by face
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         const double nxf = fnx[f], nyf = fny[f];
         double lam = 0.0;
-        double uP[Nfp], vP[Nfp], hq[Nfp], huq[Nfp], hvq[Nfp];
+        double uM[Nfp], vM[Nfp], uP[Nfp], vP[Nfp], hq[Nfp], huq[Nfp], hvq[Nfp];
 #pragma unroll
         for (int n = 0; n < Nfp; ++n) {
             const int j = f * Nfp + n, m = E::fmask(f, n);
+            const double rM = 1.0 / h[m];
+            uM[n] = hu[m] * rM;
+            vM[n] = hv[m] * rM;
+            const double spdM = sqrt(uM[n] * uM[n] + vM[n] * vM[n]) + sqrt(g * h[m]);
             hq[n] = hP[j];
             huq[n] = huP[j];
             hvq[n] = hvP[j];
@@ -117,15 +113,14 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             uP[n] = huq[n] * r;
             vP[n] = hvq[n] * r;
             const double spdP = sqrt(uP[n] * uP[n] + vP[n] * vP[n]) + sqrt(g * hq[n]);
-            lam = fmax(lam, fmax(spd[m], spdP));
+            lam = fmax(lam, fmax(spdM, spdP));
         }
         const double half_fs = 0.5 * fsc[f];
 #pragma unroll
         for (int n = 0; n < Nfp; ++n) {
             const int j = f * Nfp + n, m = E::fmask(f, n);
-            const double uM = hu[m] * rh[m], vM = hv[m] * rh[m];
             const double prM = halfg * h[m] * h[m], prP = halfg * hq[n] * hq[n];
-            const double F2M = hu[m] * uM + prM, G2M = hu[m] * vM, G3M = hv[m] * vM + prM;
+            const double F2M = hu[m] * uM[n] + prM, G2M = hu[m] * vM[n], G3M = hv[m] * vM[n] + prM;
             const double F2P = huq[n] * uP[n] + prP, G2P = huq[n] * vP[n], G3P = hvq[n] * vP[n] + prP;
             const double dh = h[m] - hq[n], dhu = hu[m] - huq[n], dhv = hv[m] - hvq[n];
             const double s1 = half_fs * (dhu * nxf + dhv * nyf - lam * dh);
@@ -165,7 +160,11 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     // ---- volume term, one input node at a time
 #pragma unroll
     for (int m = 0; m < Np; ++m) {
-        const double u = hu[m] * rh[m], v = hv[m] * rh[m];
+        // The reciprocal is recomputed here (from h * 1.0 with a run-time 1.0, so the compiler
+        // cannot reuse the surface term's value): keeping Np reciprocals live across the
+        // surface term costs more in register traffic than Np divisions.
+        const double r = 1.0 / (h[m] * p.one);
+        const double u = hu[m] * r, v = hv[m] * r;
         const double pr = halfg * h[m] * h[m];
         const double F2 = hu[m] * u + pr, G2 = hu[m] * v, G3 = hv[m] * v + pr;
         const double a1 = -(rx * hu[m] + ry * hv[m]), b1 = -(sx * hu[m] + sy * hv[m]);

@@ -208,6 +208,7 @@ struct bdg_sw2d {
         p.kbegin = 0;
         p.kend = numOwned;
         p.g = g;
+        p.one = 1.0;
         return p;
     }
 

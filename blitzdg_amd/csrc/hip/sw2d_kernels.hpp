@@ -69,6 +69,7 @@ struct StageParams {
     int kbegin, kend;    // element slots [kbegin, kend) this launch updates
     double g;
     double ca, cb, cc;
+    double one;          // 1.0 (run-time constant used to stop value reuse across phases)
 };
 
 template <int N, int MODE, bool FILTER>
