@@ -172,6 +172,7 @@ def run_distributed(args):
         dist.all_reduce(wall, op=dist.ReduceOp.MAX)
         wall = wall.item()
         d.compute_dt(CFL)  # blow-up check
+        counts = d.halo_counts()
         if rank == 0:
             K, Np = d.global_elements, d.Np
             bytes_elem = algorithmic_bytes_per_element(ORDER)
@@ -188,12 +189,13 @@ def run_distributed(args):
                                        f"triangles, N=4, partitioned into {world} parts (RCB), ghost-element "
                                        "halo over RCCL overlapped with interior elements",
                            "order": ORDER, "elements": K, "fields": 3, "parallelism": f"elem-partition x{world}",
-                           "halo_elements_per_rank": d.halo_counts()},
+                           "rank0_partition": counts},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                              "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
                              "note": "whole-job wall time incl. halo exchange, not a per-kernel figure"},
             }
             print(json.dumps(line), flush=True)
+        d.close()
     finally:
         dist.destroy_process_group()
 
@@ -206,7 +208,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("BDG_BENCH_FORCE_DISTRIBUTED") == "1":
         run_distributed(args)
     else:
         run_single(args)

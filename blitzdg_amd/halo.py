@@ -1,0 +1,254 @@
+"""Multi-GPU execution of the sw2d path: element partition + ghost-element halo.
+
+The reference has no parallel path: ``MeshManager::partitionMesh`` only produces METIS
+partition vectors that nothing consumes (reference src/MeshManager.cpp:491-544). This module
+is the MI355X-native consumer of such a vector: one process per GPU, each owning the elements
+``epart == rank`` plus one layer of ghost elements, renumbered locally as
+
+    [ interior | partition-boundary | ghost ]
+
+so that (a) ``vmapP`` of an owned element never needs a branch -- ghosts are ordinary elements
+of the local mesh -- and (b) a stage is: pack boundary state -> RCCL send/recv to the
+neighbour ranks (xGMI is point-to-point: each pair has its own link, messages are tens of KB,
+latency-bound) -> meanwhile the interior elements compute -> unpack ghosts -> boundary
+elements compute. No collective sits on the per-stage path; the adaptive time step needs one
+8-byte all-reduce per step.
+
+``HaloPlan`` / ``build_plan`` are pure NumPy (tested on CPU with gloo, world_size 2);
+``DistributedSw2d`` drives the HIP solver through the C ABI and torch.distributed.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class HaloPlan:
+    rank: int
+    world: int
+    own_global: np.ndarray        # (K_own,)  global ids of owned elements, local order [interior|boundary]
+    halo_global: np.ndarray       # (K_halo,) global ids of ghost elements, grouped by owner, ascending
+    num_interior: int
+    send_local: np.ndarray        # (n_send,) local slots of owned elements to send, grouped by peer
+    send_slices: list = field(default_factory=list)   # [(peer, start, count)] into send_local
+    recv_slices: list = field(default_factory=list)   # [(peer, start, count)] into the ghost slots
+    local_EToV: np.ndarray = None  # (K_own + K_halo, 3) local vertex ids
+    local_verts: np.ndarray = None  # (Nv_loc, 3)
+    local_bctype: np.ndarray = None  # (K_loc, 3) BC tags of the GLOBAL mesh for owned elements, 0 for ghosts
+
+    @property
+    def num_owned(self):
+        return int(self.own_global.size)
+
+    @property
+    def num_halo(self):
+        return int(self.halo_global.size)
+
+    @property
+    def local_to_global(self):
+        return np.concatenate([self.own_global, self.halo_global])
+
+
+def build_plan(EToV, Vert, EToE, epart, rank, world, bctype=None):
+    """Halo plan of `rank` from the global mesh tables and an element partition vector."""
+    EToV = np.asarray(EToV).reshape(-1, 3)
+    EToE = np.asarray(EToE).reshape(-1, 3)
+    Vert = np.asarray(Vert, dtype=np.float64)
+    epart = np.asarray(epart).reshape(-1)
+    own = np.flatnonzero(epart == rank)
+    nb = EToE[own]                    # (K_own, 3) neighbour elements (self on physical boundaries)
+    nb_owner = epart[nb]
+    remote = nb_owner != rank
+    is_boundary = remote.any(axis=1)
+    own_order = np.concatenate([own[~is_boundary], own[is_boundary]])
+    num_interior = int((~is_boundary).sum())
+    slot_of = np.full(epart.size, -1, dtype=np.int64)
+    slot_of[own_order] = np.arange(own_order.size)
+
+    # ghosts: remote neighbours, grouped by owner rank then ascending global id
+    ghost_ids = np.unique(nb[remote])
+    ghost_owner = epart[ghost_ids]
+    order = np.lexsort((ghost_ids, ghost_owner))
+    ghost_ids, ghost_owner = ghost_ids[order], ghost_owner[order]
+    recv_slices, start = [], 0
+    for peer in np.unique(ghost_owner):
+        cnt = int((ghost_owner == peer).sum())
+        recv_slices.append((int(peer), start, cnt))
+        start += cnt
+
+    # what each peer needs from us: our elements adjacent to one of theirs, ascending global id
+    send_local, send_slices, start = [], [], 0
+    for peer in np.unique(nb_owner[remote]):
+        mine = np.unique(own[(nb_owner == peer).any(axis=1)])
+        send_local.append(slot_of[mine])
+        send_slices.append((int(peer), start, int(mine.size)))
+        start += mine.size
+    send_local = np.concatenate(send_local).astype(np.int32) if send_local else np.zeros(0, dtype=np.int32)
+
+    loc2glob = np.concatenate([own_order, ghost_ids])
+    ev = EToV[loc2glob]
+    verts_used, inv = np.unique(ev, return_inverse=True)
+    local_EToV = inv.reshape(ev.shape).astype(np.int32)
+    local_verts = Vert.reshape(-1, Vert.shape[-1] if Vert.ndim == 2 else 3)[verts_used]
+    local_bc = np.zeros((loc2glob.size, 3), dtype=np.int32)
+    if bctype is not None:
+        local_bc[:own_order.size] = np.asarray(bctype).reshape(-1, 3)[own_order]
+    return HaloPlan(rank=rank, world=world, own_global=own_order.astype(np.int64), halo_global=ghost_ids.astype(np.int64),
+                    num_interior=num_interior, send_local=send_local, send_slices=send_slices,
+                    recv_slices=recv_slices, local_EToV=local_EToV, local_verts=local_verts, local_bctype=local_bc)
+
+
+def exchange_ops(plan, sendbuf, recvbuf, dist):
+    """P2P ops of one halo exchange. sendbuf: (n_send, width), recvbuf: (K_halo, width) tensors
+    (CPU with gloo, CUDA with nccl/RCCL). Returns the list for dist.batch_isend_irecv."""
+    ops = []
+    for peer, start, count in plan.recv_slices:
+        ops.append(dist.P2POp(dist.irecv, recvbuf[start:start + count], peer))
+    for peer, start, count in plan.send_slices:
+        ops.append(dist.P2POp(dist.isend, sendbuf[start:start + count], peer))
+    return ops
+
+
+def build_local_mesh(plan):
+    """MeshManager of the rank-local mesh (owned + ghost elements). Ghost elements' outer faces
+    become walls of the local mesh; they are never updated, so that is immaterial. Owned
+    elements keep the BC tags of the global mesh."""
+    from . import pyblitzdg as dg
+    mesh = dg.MeshManager()
+    mesh.buildMesh(plan.local_EToV, plan.local_verts)
+    got = mesh.elements
+    if not np.array_equal(got, plan.local_EToV):
+        raise RuntimeError("local mesh was re-oriented: the global mesh must be counter-clockwise")
+    bc = mesh.bcType
+    bc[:plan.num_owned] = plan.local_bctype[:plan.num_owned]
+    mesh.setBCType(bc)
+    return mesh
+
+
+class DistributedSw2d:
+    """sw2d on `world` GPUs (one process each): owned elements on this rank's device, ghosts
+    refreshed every stage over torch.distributed (backend "nccl" = RCCL over xGMI)."""
+
+    def __init__(self, plan, order, g=9.81, device=0, filter_args=None):
+        import torch
+        import torch.distributed as dist
+
+        from . import pyblitzdg as dg
+        from . import sw2d
+        from ._capi import check, lib, ptr
+
+        self._torch, self._dist, self._lib, self._check = torch, dist, lib, check
+        self.plan = plan
+        self.order = order
+        self.mesh = build_local_mesh(plan)
+        self.nodes = dg.TriangleNodesProvisioner(order, self.mesh)
+        if filter_args is not None:
+            self.nodes.buildFilter(*filter_args)
+        self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device)
+        self.Np, self.K_loc = self.solver.Np, self.solver.K
+        send = np.ascontiguousarray(plan.send_local, dtype=np.int32)
+        check(lib.bdg_sw2d_set_partition(self.solver._h, plan.num_interior, plan.num_owned, ptr(send), send.size))
+        width = 3 * self.Np
+        dev = torch.device("cuda", device)
+        self.sendbuf = torch.zeros((max(send.size, 1), width), dtype=torch.float64, device=dev)
+        self.recvbuf = torch.zeros((max(plan.num_halo, 1), width), dtype=torch.float64, device=dev)
+        # Transport: RCCL moves the device buffers directly. With the CPU-only `gloo` backend (used
+        # to exercise several ranks on ONE GPU in tests) the buffers are staged through host memory.
+        self.host_staged = dist.get_backend() != "nccl"
+        if self.host_staged:
+            self.send_host = torch.zeros_like(self.sendbuf, device="cpu").pin_memory()
+            self.recv_host = torch.zeros_like(self.recvbuf, device="cpu").pin_memory()
+        # the solver launches on its own stream: make it torch's current stream around the
+        # exchange so RCCL orders itself after the pack and before the unpack
+        self.stream = torch.cuda.ExternalStream(lib.bdg_sw2d_stream(self.solver._h), device=dev)
+        counts = torch.tensor([plan.num_owned], dtype=torch.int64, device="cpu" if self.host_staged else dev)
+        dist.all_reduce(counts)
+        self.global_elements = int(counts.item())
+
+    @classmethod
+    def box(cls, nx, ny, order, g=9.81, device=0, x0=-1.0, x1=1.0, y0=-1.0, y1=1.0):
+        """Every rank builds the (cheap) global box mesh and the same RCB partition, then keeps
+        only its part."""
+        import torch.distributed as dist
+
+        from . import pyblitzdg as dg
+        rank, world = dist.get_rank(), dist.get_world_size()
+        mesh = dg.MeshManager()
+        mesh.buildBoxMesh(nx, ny, x0, x1, y0, y1)
+        mesh.partitionMesh(world)
+        plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, rank, world,
+                          bctype=mesh.bcType)
+        del mesh
+        return cls(plan, order, g=g, device=device)
+
+    def close(self):
+        """Release in a safe order: torch's wrapper of the solver's stream and the exchange
+        buffers first, the solver (which owns and destroys that stream) last."""
+        solver = getattr(self, "solver", None)
+        if solver is None:
+            return
+        try:
+            solver.synchronize()
+        except Exception:
+            pass
+        self.stream = None
+        self.sendbuf = self.recvbuf = None
+        if getattr(self, "host_staged", False):
+            self.send_host = self.recv_host = None
+        self.solver = None
+        solver.close()
+
+    def __del__(self):
+        self.close()
+
+    def halo_counts(self):
+        return {"owned": self.plan.num_owned, "interior": self.plan.num_interior, "ghost": self.plan.num_halo,
+                "sent": int(self.plan.send_local.size)}
+
+    def set_initial_state(self, fn):
+        ctx = self.nodes.dgContext()
+        h, hu, hv = fn(ctx.x, ctx.y)   # owned and ghost elements alike: ghosts start current
+        self.solver.setState(h, hu, hv)
+
+    def compute_dt(self, CFL):
+        torch, dist = self._torch, self._dist
+        dt, _ = self.solver.computeDt(CFL)   # reduction over owned elements only
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if self.host_staged else self.sendbuf.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def lserk4_stage(self, dt):
+        torch, dist, lib, check = self._torch, self._dist, self._lib, self._check
+        h = self.solver._h
+        if self.host_staged:
+            return self._lserk4_stage_host_staged(dt)
+        with torch.cuda.stream(self.stream):
+            check(lib.bdg_sw2d_halo_pack(h, self.sendbuf.data_ptr()))
+            ops = exchange_ops(self.plan, self.sendbuf, self.recvbuf, dist)
+            works = dist.batch_isend_irecv(ops) if ops else []
+            check(lib.bdg_sw2d_lserk4_stage_part(h, dt, 0))       # interior: overlaps the exchange
+            for w in works:
+                w.wait()                                            # stream-level wait, host does not block
+            check(lib.bdg_sw2d_halo_unpack(h, self.recvbuf.data_ptr()))
+            check(lib.bdg_sw2d_lserk4_stage_part(h, dt, 1))       # partition-boundary elements, advance
+
+    def _lserk4_stage_host_staged(self, dt):
+        torch, dist, lib, check = self._torch, self._dist, self._lib, self._check
+        h = self.solver._h
+        with torch.cuda.stream(self.stream):
+            check(lib.bdg_sw2d_halo_pack(h, self.sendbuf.data_ptr()))
+            self.send_host.copy_(self.sendbuf, non_blocking=True)
+            check(lib.bdg_sw2d_lserk4_stage_part(h, dt, 0))
+            self.stream.synchronize()
+            ops = exchange_ops(self.plan, self.send_host, self.recv_host, dist)
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            self.recvbuf.copy_(self.recv_host, non_blocking=True)
+            check(lib.bdg_sw2d_halo_unpack(h, self.recvbuf.data_ptr()))
+            check(lib.bdg_sw2d_lserk4_stage_part(h, dt, 1))
+
+    def owned_state(self):
+        """(global ids, h, hu, hv) of the owned elements."""
+        h, hu, hv = self.solver.getState()
+        n = self.plan.num_owned
+        return self.plan.own_global, h[:, :n], hu[:, :n], hv[:, :n]
