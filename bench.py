@@ -142,7 +142,56 @@ def run_single(args):
     print(json.dumps(line), flush=True)
 
 
-def run_distributed(args):
+def distributed_line(world, steps, warmup, wall, K, Np, counts, transport):
+    bytes_elem = algorithmic_bytes_per_element(ORDER)
+    achieved = bytes_elem * K * steps / wall / 1e9
+    return {
+        "metric": "element-DOF updates/sec (sw2d RHS + LSERK4 stage, N=4, 1M tris)",
+        "value": Np * K * steps / wall,
+        "unit": "element-DOF updates/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": wall / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "sw2d RHS + fused LSERK4 stage, synthetic box 1000x500 cells = 1e6 "
+                               f"triangles, N=4, partitioned into {world} parts (RCB), ghost-element "
+                               "halo over RCCL overlapped with interior elements",
+                   "order": ORDER, "elements": K, "fields": 3, "parallelism": f"elem-partition x{world}",
+                   "transport": transport, "rank0_partition": counts},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
+                     "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
+                     "note": "whole-job wall time incl. halo exchange, not a per-kernel figure"},
+    }
+
+
+def run_distributed_native(args):
+    """One process per GPU; RCCL driven from the C++ library (no PyTorch in the workers). The
+    timed region is bracketed by an all-rank barrier + device synchronisation on both sides and
+    the maximum over ranks is taken."""
+    from blitzdg_amd.halo import NativeDistributedSw2d
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    d = NativeDistributedSw2d.box(NX, NY, ORDER, rank, world, g=G, device=local_rank)
+    try:
+        d.set_initial_state(initial_state)
+        dt = d.compute_dt(CFL)
+        d.lserk4_stages(dt, args.warmup)
+        d.barrier()
+        t0 = time.perf_counter()
+        d.lserk4_stages(dt, args.steps)
+        d.barrier()
+        wall = d.allreduce_max(time.perf_counter() - t0)
+        d.compute_dt(CFL)  # blow-up check (global)
+        if rank == 0:
+            print(json.dumps(distributed_line(world, args.steps, args.warmup, wall, d.global_elements, d.Np,
+                                              d.halo_counts(), "native RCCL (ncclSend/ncclRecv groups)")), flush=True)
+    finally:
+        d.close()
+
+
+def run_distributed_torch(args):
     import torch
     import torch.distributed as dist
 
@@ -174,30 +223,18 @@ def run_distributed(args):
         d.compute_dt(CFL)  # blow-up check
         counts = d.halo_counts()
         if rank == 0:
-            K, Np = d.global_elements, d.Np
-            bytes_elem = algorithmic_bytes_per_element(ORDER)
-            achieved = bytes_elem * K * args.steps / wall / 1e9
-            line = {
-                "metric": "element-DOF updates/sec (sw2d RHS + LSERK4 stage, N=4, 1M tris)",
-                "value": Np * K * args.steps / wall,
-                "unit": "element-DOF updates/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": wall / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-                "dtype": "f64", "data": "synthetic",
-                "config": {"workload": "sw2d RHS + fused LSERK4 stage, synthetic box 1000x500 cells = 1e6 "
-                                       f"triangles, N=4, partitioned into {world} parts (RCB), ghost-element "
-                                       "halo over RCCL overlapped with interior elements",
-                           "order": ORDER, "elements": K, "fields": 3, "parallelism": f"elem-partition x{world}",
-                           "rank0_partition": counts},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
-                             "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
-                             "note": "whole-job wall time incl. halo exchange, not a per-kernel figure"},
-            }
-            print(json.dumps(line), flush=True)
+            print(json.dumps(distributed_line(world, args.steps, args.warmup, wall, d.global_elements, d.Np, counts,
+                                              "torch.distributed nccl (RCCL) batch_isend_irecv")), flush=True)
         d.close()
     finally:
         dist.destroy_process_group()
+
+
+def run_distributed(args):
+    if os.environ.get("BDG_TRANSPORT", "native") == "torch":
+        run_distributed_torch(args)
+    else:
+        run_distributed_native(args)
 
 
 def main():

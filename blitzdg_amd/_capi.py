@@ -116,6 +116,12 @@ _SIGNATURES = {
     "bdg_sw2d_halo_pack": (c_int, [_P, _P]),
     "bdg_sw2d_halo_unpack": (c_int, [_P, _P]),
     "bdg_sw2d_lserk4_stage_part": (c_int, [_P, c_double, c_int]),
+    "bdg_comm_unique_id": (c_int, [_P, c_int]),
+    "bdg_sw2d_comm_init": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int]),
+    "bdg_sw2d_lserk4_stages_exchanged": (c_int, [_P, c_double, c_int]),
+    "bdg_sw2d_compute_dt_global": (c_int, [_P, c_double, POINTER(c_double), POINTER(c_double)]),
+    "bdg_sw2d_allreduce_max": (c_int, [_P, c_double, POINTER(c_double)]),
+    "bdg_sw2d_barrier": (c_int, [_P]),
     "bdg_sw2d_rhs_resident": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_synchronize": (c_int, [_P]),
     "bdg_sw2d_time_lserk4_stages": (c_int, [_P, c_double, c_int, POINTER(c_float)]),

@@ -15,9 +15,12 @@
 #include "../host/capi_internal.hpp"
 #include "blitzdg/LSERK4.hpp"
 #include "sw2d_launch.hpp"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <limits>
 #include <queue>
 #include <string>
 #include <vector>
@@ -126,6 +129,51 @@ void hipCheck(hipError_t e, const char* what) {
     if (e != hipSuccess) throw hip_error(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// RCCL is bound at run time (dlopen) the first time a communicator is asked for, so the
+// library itself has no load-time dependency on it and single-GPU users never load it.
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi& rccl() {
+    static RcclApi api;
+    if (api.handle) return api;
+    const char* names[] = {"librccl.so.1", "librccl.so"};
+    for (const char* n : names) {
+        api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) throw bdg_detail::hip_error(std::string("cannot load RCCL: ") + dlerror());
+    auto sym = [&](const char* name) {
+        void* p = dlsym(api.handle, name);
+        if (!p) throw bdg_detail::hip_error(std::string("RCCL symbol missing: ") + name);
+        return p;
+    };
+    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
+    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    return api;
+}
+
+void ncclCheck(ncclResult_t r, const char* what) {
+    if (r != ncclSuccess) throw bdg_detail::hip_error(std::string(what) + ": " + rccl().GetErrorString(r));
+}
+
 template <typename T>
 struct DevBuf {
     T* p = nullptr;
@@ -161,12 +209,24 @@ struct bdg_sw2d {
     bool affine = false;
     DevBuf<int> vmapP, perm, istage, sendSlots;
     int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
+    // native halo exchange (RCCL over xGMI): one send and one receive range per neighbour rank
+    struct Peer { int rank, sendStart, sendCount, recvStart, recvCount; };
+    std::vector<Peer> peers;
+    ncclComm_t comm = nullptr;
+    int commRank = 0, commWorld = 1;
+    hipStream_t commStream = nullptr;
+    hipEvent_t evPacked = nullptr, evExchanged = nullptr;
+    DevBuf<double> sendBuf, recvBuf, scalarBuf;
     double* qcur = nullptr;  // current state
     double* qalt = nullptr;  // the other buffer
     long long stageCount = 0; // LSERK stage counter (stage index = count % 5)
     std::vector<int> permHost; // caller element -> device slot (empty = identity)
 
     ~bdg_sw2d() {
+        if (comm) (void)rccl().CommDestroy(comm);
+        if (evPacked) (void)hipEventDestroy(evPacked);
+        if (evExchanged) (void)hipEventDestroy(evExchanged);
+        if (commStream) (void)hipStreamDestroy(commStream);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -250,6 +310,69 @@ struct bdg_sw2d {
         ++stageCount;
     }
     double dtStage = 0.0;
+
+    void launchPack(double* buf) {
+        if (numSend == 0) return;
+        const int rows = 3 * Np;
+        const long long n = static_cast<long long>(numSend) * rows;
+        hipLaunchKernelGGL(bdg_dev::halo_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream,
+                           qcur, buf, sendSlots.p, numSend, rows, ld);
+        hipCheck(hipGetLastError(), "halo_pack_kernel");
+    }
+    void launchUnpack(const double* buf) {
+        const int ghosts = K - numOwned;
+        if (ghosts == 0) return;
+        const int rows = 3 * Np;
+        const long long n = static_cast<long long>(ghosts) * rows;
+        hipLaunchKernelGGL(bdg_dev::halo_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                           stream, qcur, buf, numOwned, ghosts, rows, ld);
+        hipCheck(hipGetLastError(), "halo_unpack_kernel");
+    }
+
+    // One LSERK4 stage of a partitioned run, all on the device:
+    //   compute stream: pack -> [interior elements] ............ wait -> unpack -> [boundary elements]
+    //   comm stream:      wait(pack) -> grouped ncclSend/ncclRecv with every neighbour -> signal
+    // The interior launch hides the exchange; buffers are reused safely because each stage's
+    // pack is ordered after the previous stage's exchange completed on the compute stream.
+    void launchLserkStageExchanged() {
+        if (!comm) throw arg_error("no communicator: call bdg_sw2d_comm_init first");
+        const int rows = 3 * Np;
+        launchPack(sendBuf.p);
+        hipCheck(hipEventRecord(evPacked, stream), "hipEventRecord");
+        hipCheck(hipStreamWaitEvent(commStream, evPacked, 0), "hipStreamWaitEvent");
+        if (!peers.empty()) {
+            RcclApi& nc = rccl();
+            ncclCheck(nc.GroupStart(), "ncclGroupStart");
+            for (const Peer& pr : peers) {
+                if (pr.recvCount > 0)
+                    ncclCheck(nc.Recv(recvBuf.p + static_cast<size_t>(pr.recvStart) * rows,
+                                      static_cast<size_t>(pr.recvCount) * rows, ncclDouble, pr.rank, comm, commStream),
+                              "ncclRecv");
+                if (pr.sendCount > 0)
+                    ncclCheck(nc.Send(sendBuf.p + static_cast<size_t>(pr.sendStart) * rows,
+                                      static_cast<size_t>(pr.sendCount) * rows, ncclDouble, pr.rank, comm, commStream),
+                              "ncclSend");
+            }
+            ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
+        }
+        hipCheck(hipEventRecord(evExchanged, commStream), "hipEventRecord");
+        launchLserkStage(0);                                   // interior elements: overlap the exchange
+        hipCheck(hipStreamWaitEvent(stream, evExchanged, 0), "hipStreamWaitEvent");
+        launchUnpack(recvBuf.p);
+        launchLserkStage(1);                                   // partition-boundary elements, advance
+    }
+
+    // max (or min) of one double over all ranks, through the device
+    double allReduceScalar(double v, bool takeMax) {
+        if (!comm || commWorld == 1) return v;
+        hipCheck(hipMemcpyAsync(scalarBuf.p, &v, sizeof(double), hipMemcpyHostToDevice, stream), "H2D copy");
+        ncclCheck(rccl().AllReduce(scalarBuf.p, scalarBuf.p + 1, 1, ncclDouble, takeMax ? ncclMax : ncclMin, comm, stream),
+                  "ncclAllReduce");
+        double out = 0.0;
+        hipCheck(hipMemcpyAsync(&out, scalarBuf.p + 1, sizeof(double), hipMemcpyDeviceToHost, stream), "D2H copy");
+        hipCheck(hipStreamSynchronize(stream), "allreduce sync");
+        return out;
+    }
 
     // q1 = q + dt/2 R(q);  q = q + dt R(q1)   (reference src/sw2d-simple/main.cpp:132-151)
     void launchRk2Step(double dt, bool filter) {
@@ -784,6 +907,99 @@ int bdg_sw2d_rhs_resident(bdg_sw2d* s, double* r1, double* r2, double* r3) {
         s->downloadRows(s->aux.p, r1, s->Np);
         s->downloadRows(s->aux.p + pl, r2, s->Np);
         s->downloadRows(s->aux.p + 2 * pl, r3, s->Np);
+    });
+}
+
+int bdg_comm_unique_id(void* id_out, int capacity) {
+    return guard([&] {
+        if (!id_out || capacity < static_cast<int>(sizeof(ncclUniqueId)))
+            throw arg_error("bdg_comm_unique_id: need a buffer of at least 128 bytes");
+        ncclUniqueId id;
+        ncclCheck(rccl().GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id_out, &id, sizeof(id));
+    });
+}
+
+int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, const int* peer_ranks,
+                       const int* send_start, const int* send_count, const int* recv_start, const int* recv_count,
+                       int num_peers) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_comm_init");
+        if (!unique_id || world < 1 || rank < 0 || rank >= world || num_peers < 0 ||
+            (num_peers > 0 && (!peer_ranks || !send_start || !send_count || !recv_start || !recv_count)))
+            throw arg_error("bdg_sw2d_comm_init: bad argument");
+        if (s->comm) throw arg_error("bdg_sw2d_comm_init: communicator already initialised");
+        const int ghosts = s->K - s->numOwned;
+        std::vector<bdg_sw2d::Peer> peers;
+        for (int i = 0; i < num_peers; ++i) {
+            const bdg_sw2d::Peer p{peer_ranks[i], send_start[i], send_count[i], recv_start[i], recv_count[i]};
+            if (p.rank < 0 || p.rank >= world || p.rank == rank || p.sendStart < 0 || p.sendCount < 0 ||
+                p.sendStart + p.sendCount > s->numSend || p.recvStart < 0 || p.recvCount < 0 ||
+                p.recvStart + p.recvCount > ghosts)
+                throw arg_error("bdg_sw2d_comm_init: peer ranges do not fit the partition set with bdg_sw2d_set_partition");
+            peers.push_back(p);
+        }
+        s->use();
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof(id));
+        ncclCheck(rccl().CommInitRank(&s->comm, world, id, rank), "ncclCommInitRank");
+        s->commRank = rank;
+        s->commWorld = world;
+        s->peers = peers;
+        hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
+        hipCheck(hipEventCreateWithFlags(&s->evPacked, hipEventDisableTiming), "hipEventCreate");
+        hipCheck(hipEventCreateWithFlags(&s->evExchanged, hipEventDisableTiming), "hipEventCreate");
+        const size_t rows = 3 * static_cast<size_t>(s->Np);
+        s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
+        s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
+        s->scalarBuf.alloc(2, s->bytes);
+    });
+}
+
+int bdg_sw2d_lserk4_stages_exchanged(bdg_sw2d* s, double dt, int num_stages) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_lserk4_stages_exchanged");
+        if (num_stages < 0) throw arg_error("bdg_sw2d_lserk4_stages_exchanged: num_stages < 0");
+        s->use();
+        s->dtStage = dt;
+        for (int i = 0; i < num_stages; ++i) s->launchLserkStageExchanged();
+    });
+}
+
+int bdg_sw2d_compute_dt_global(bdg_sw2d* s, double cfl, double* dt, double* eta_max) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_compute_dt_global");
+        s->use();
+        double r[2];
+        s->reduceDt(r);
+        // NaN does not survive a max-reduction reliably: send it as +inf
+        const double big = std::numeric_limits<double>::infinity();
+        const double f = s->allReduceScalar(std::isnan(r[0]) ? big : r[0], true);
+        const double e = s->allReduceScalar(std::isnan(r[1]) ? big : r[1], true);
+        if (eta_max) *eta_max = e;
+        if (dt) *dt = cfl / ((s->N + 1) * (s->N + 1) * 0.5 * f);
+        if (std::isinf(f) || std::isinf(e) || std::fabs(e) > 1e8)
+            throw unstable_error("A numerical instability has occurred!");
+    });
+}
+
+int bdg_sw2d_allreduce_max(bdg_sw2d* s, double value, double* out) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_allreduce_max");
+        if (!out) throw arg_error("bdg_sw2d_allreduce_max: out is NULL");
+        s->use();
+        *out = s->allReduceScalar(value, true);
+    });
+}
+
+int bdg_sw2d_barrier(bdg_sw2d* s) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_barrier");
+        s->use();
+        hipCheck(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+        if (s->commStream) hipCheck(hipStreamSynchronize(s->commStream), "hipStreamSynchronize");
+        (void)s->allReduceScalar(0.0, true); // every rank arrives before anyone leaves
+        hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
     });
 }
 

@@ -125,9 +125,135 @@ def build_local_mesh(plan):
     return mesh
 
 
+def file_rendezvous(rank, world, make_id, timeout=300.0):
+    """Hands rank 0's 128-byte RCCL id to every rank of a single-node job through a file in
+    /tmp. The name is unique per launch: all ranks are children of one launcher process (its
+    pid) and share MASTER_PORT. Rank 0 removes the file once every rank has joined
+    (see NativeDistributedSw2d)."""
+    import os
+    import time
+    path = f"/tmp/bdg_rccl_id_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{world}"
+    if rank == 0:
+        uid = make_id()
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)  # atomic: readers never see a partial id
+        return uid, path
+    deadline = time.time() + timeout
+    while time.time() < deadline:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid, path
+        except FileNotFoundError:
+            pass
+        time.sleep(0.02)
+    raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout} s")
+
+
+class NativeDistributedSw2d:
+    """sw2d on `world` GPUs with the exchange driven entirely by the C++ library: grouped
+    ncclSend/ncclRecv on a communication stream, overlapped with the interior elements, whole
+    stage loops issued by one C call (no per-stage Python). PyTorch is not involved."""
+
+    def __init__(self, plan, order, g=9.81, device=0, unique_id=None):
+        import ctypes
+        import os
+
+        from . import pyblitzdg as dg
+        from . import sw2d
+        from ._capi import byref, c_double, check, lib, ptr
+
+        self._lib, self._check, self._byref, self._c_double = lib, check, byref, c_double
+        self.plan, self.order = plan, order
+        self.mesh = build_local_mesh(plan)
+        self.nodes = dg.TriangleNodesProvisioner(order, self.mesh)
+        self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device)
+        self.Np = self.solver.Np
+        send = np.ascontiguousarray(plan.send_local, dtype=np.int32)
+        check(lib.bdg_sw2d_set_partition(self.solver._h, plan.num_interior, plan.num_owned, ptr(send), send.size))
+
+        id_path = None
+        if unique_id is None:
+            def make_id():
+                buf = ctypes.create_string_buffer(128)
+                check(lib.bdg_comm_unique_id(buf, 128))
+                return buf.raw
+            unique_id, id_path = file_rendezvous(plan.rank, plan.world, make_id)
+        recv_of = {peer: (start, count) for peer, start, count in plan.recv_slices}
+        send_of = {peer: (start, count) for peer, start, count in plan.send_slices}
+        peers = sorted(set(recv_of) | set(send_of))
+        arr = lambda vals: np.ascontiguousarray(vals, dtype=np.int32)  # noqa: E731
+        pr = arr(peers)
+        ss, sc = arr([send_of.get(p, (0, 0))[0] for p in peers]), arr([send_of.get(p, (0, 0))[1] for p in peers])
+        rs, rc = arr([recv_of.get(p, (0, 0))[0] for p in peers]), arr([recv_of.get(p, (0, 0))[1] for p in peers])
+        idbuf = ctypes.create_string_buffer(unique_id, 128)
+        check(lib.bdg_sw2d_comm_init(self.solver._h, plan.rank, plan.world, idbuf, ptr(pr), ptr(ss), ptr(sc), ptr(rs),
+                                     ptr(rc), len(peers)))
+        self.barrier()
+        if id_path is not None and plan.rank == 0:
+            try:
+                os.remove(id_path)
+            except OSError:
+                pass
+        self.global_elements = None
+
+    @classmethod
+    def box(cls, nx, ny, order, rank, world, g=9.81, device=0, x0=-1.0, x1=1.0, y0=-1.0, y1=1.0):
+        from . import pyblitzdg as dg
+        mesh = dg.MeshManager()
+        mesh.buildBoxMesh(nx, ny, x0, x1, y0, y1)
+        mesh.partitionMesh(world)
+        plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, rank, world,
+                          bctype=mesh.bcType)
+        total = mesh.numElements
+        del mesh
+        self = cls(plan, order, g=g, device=device)
+        self.global_elements = total
+        return self
+
+    def close(self):
+        solver, self.solver = getattr(self, "solver", None), None
+        if solver is not None:
+            solver.close()
+
+    def halo_counts(self):
+        return {"owned": self.plan.num_owned, "interior": self.plan.num_interior, "ghost": self.plan.num_halo,
+                "sent": int(self.plan.send_local.size), "peers": len(self.plan.recv_slices)}
+
+    def set_initial_state(self, fn):
+        ctx = self.nodes.dgContext()
+        self.solver.setState(*fn(ctx.x, ctx.y))
+
+    def compute_dt(self, CFL):
+        dt, em = self._c_double(), self._c_double()
+        self._check(self._lib.bdg_sw2d_compute_dt_global(self.solver._h, float(CFL), self._byref(dt), self._byref(em)))
+        return dt.value
+
+    def lserk4_stages(self, dt, nstages):
+        self._check(self._lib.bdg_sw2d_lserk4_stages_exchanged(self.solver._h, float(dt), int(nstages)))
+
+    def allreduce_max(self, value):
+        out = self._c_double()
+        self._check(self._lib.bdg_sw2d_allreduce_max(self.solver._h, float(value), self._byref(out)))
+        return out.value
+
+    def barrier(self):
+        self._check(self._lib.bdg_sw2d_barrier(self.solver._h))
+
+    def owned_state(self):
+        h, hu, hv = self.solver.getState()
+        n = self.plan.num_owned
+        return self.plan.own_global, h[:, :n], hu[:, :n], hv[:, :n]
+
+
 class DistributedSw2d:
     """sw2d on `world` GPUs (one process each): owned elements on this rank's device, ghosts
-    refreshed every stage over torch.distributed (backend "nccl" = RCCL over xGMI)."""
+    refreshed every stage over torch.distributed (backend "nccl" = RCCL over xGMI).
+    Kept as the torch-plumbed alternative to NativeDistributedSw2d and as the way to run
+    several ranks on ONE GPU in tests (host-staged `gloo`)."""
 
     def __init__(self, plan, order, g=9.81, device=0, filter_args=None):
         import torch

@@ -205,6 +205,23 @@ int bdg_sw2d_halo_unpack(bdg_sw2d* s, const void* recv_buffer_device);
 /* One LSERK4 stage over part of the owned elements: 0 = interior only (does not advance the
  * stage), 1 = partition-boundary elements then advance, 2 = all owned elements then advance. */
 int bdg_sw2d_lserk4_stage_part(bdg_sw2d* s, double dt, int part);
+/* Native transport: RCCL point-to-point over xGMI, driven entirely from this library (bound
+ * with dlopen on first use). Rank 0 creates a 128-byte id and hands it to every rank by any
+ * means; each rank then gives its neighbour list: for peer i, it sends the elements
+ * send_elements[send_start[i] .. +send_count[i]) (of bdg_sw2d_set_partition) and receives
+ * recv_count[i] ghost elements into ghost slots recv_start[i].. (relative to num_owned). */
+int bdg_comm_unique_id(void* id_out, int capacity);
+int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, const int* peer_ranks,
+                       const int* send_start, const int* send_count, const int* recv_start,
+                       const int* recv_count, int num_peers);
+/* num_stages LSERK4 stages with the ghost exchange overlapped with the interior elements:
+ * pack -> {grouped ncclSend/ncclRecv on the comm stream || interior kernel} -> unpack -> boundary. */
+int bdg_sw2d_lserk4_stages_exchanged(bdg_sw2d* s, double dt, int num_stages);
+/* bdg_sw2d_compute_dt with the maxima reduced over all ranks (one 8-byte all-reduce each). */
+int bdg_sw2d_compute_dt_global(bdg_sw2d* s, double cfl, double* dt, double* eta_max);
+int bdg_sw2d_allreduce_max(bdg_sw2d* s, double value, double* out);
+/* Drains this rank's streams, meets every other rank, drains again. */
+int bdg_sw2d_barrier(bdg_sw2d* s);
 /* RHS of the resident state (owned elements valid; ghosts must be current) to host arrays. */
 int bdg_sw2d_rhs_resident(bdg_sw2d* s, double* rhs1, double* rhs2, double* rhs3);
 

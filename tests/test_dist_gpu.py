@@ -92,3 +92,42 @@ def test_distributed_matches_single_domain(tmp_path, backend, world):
             # same kernels, same per-element arithmetic: identical bits
             assert np.array_equal(p[name], r[:, ids]), name
     assert (seen == 1).all()
+
+
+_NATIVE_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+from blitzdg_amd.halo import NativeDistributedSw2d
+from test_dist_gpu import NX, NY, ORDER, NSTAGES, _fields
+assert "torch" not in sys.modules
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+d = NativeDistributedSw2d.box(NX, NY, ORDER, rank, world, device=0)
+d.set_initial_state(_fields)
+dt = 0.5 * d.compute_dt(0.65)
+d.lserk4_stages(dt, NSTAGES)
+d.barrier()
+assert d.allreduce_max(3.5) == 3.5
+ids, h, hu, hv = d.owned_state()
+np.savez(sys.argv[2], ids=ids, h=h, hu=hu, hv=hv, dt=dt, total=d.global_elements)
+d.close()
+"""
+
+
+def test_native_rccl_single_rank(tmp_path):
+    """The production transport (RCCL bound by the C++ library, no PyTorch in the process) with
+    one rank: communicator init from a file rendezvous, empty neighbour group, stream/event
+    choreography of the exchanged stage, device all-reduce."""
+    import subprocess
+    out = tmp_path / "native.npz"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", _NATIVE_SCRIPT, ROOT, str(out)], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    p = np.load(out)
+    ref = _single_domain(float(p["dt"]))
+    assert int(p["total"]) == 2 * NX * NY and np.array_equal(p["ids"], np.arange(2 * NX * NY))
+    for name, a in zip(("h", "hu", "hv"), ref):
+        assert np.array_equal(p[name], a), name
