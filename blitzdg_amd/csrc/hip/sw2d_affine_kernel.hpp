@@ -35,6 +35,41 @@ struct AffineOps {
     static constexpr int DOUBLES = OFF_LIFT + E::NFN * E::Np;
 };
 
+// 1/x to ~1 ulp for well-scaled positive x (water depths): hardware estimate + two Newton steps.
+// (The default fp64 division also rescales and fixes up denormals/infinities, which cannot
+// occur for h > 0; results differ from IEEE division by at most 1 ulp.)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// sqrt(x) for x >= 0 to ~1 ulp: rsq estimate + coupled Newton iterations on (g, h) = (sqrt x, 1/(2 sqrt x)).
+// x is clamped at 1e-290 so that x = 0 (fluid at rest) gives 1e-145 instead of 0*inf.
+__device__ __forceinline__ double fast_sqrt(double x) {
+    x = fmax(x, 1e-290);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    return g;
+}
+
+// Load/store at a wave-uniform row pointer plus a 32-bit per-lane BYTE offset: lowers to the
+// scalar-base + vector-offset addressing mode (no 64-bit vector address arithmetic per row).
+template <typename T>
+__device__ __forceinline__ T ld_row(const T* row, unsigned byteOff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + byteOff);
+}
+template <typename T>
+__device__ __forceinline__ void st_row(T* row, unsigned byteOff, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byteOff) = v;
+}
+
 template <int N, int MODE>
 __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParams p) {
     using E = Elem<N>;
@@ -42,53 +77,56 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
 
     const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
     const unsigned tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
-    const long long k = p.kbegin + static_cast<long long>(tile) * blockDim.x + threadIdx.x;
-    if (k >= p.kend) return;
+    // 32-bit element index: every row pointer below is wave-uniform (SGPR base) and the lane
+    // part is a 32-bit offset, so a load needs no 64-bit vector address arithmetic.
+    const unsigned k = static_cast<unsigned>(p.kbegin) + tile * blockDim.x + threadIdx.x;
+    if (k >= static_cast<unsigned>(p.kend)) return;
+    const unsigned k8 = k * 8u, k4 = k * 4u; // Np*ld*8 < 2^31 is checked on the host
 
     const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
     const double* __restrict__ ops = p.opsAffine; // wave-uniform reads -> scalar loads
-    const double* __restrict__ qh = p.qin + k;
+    const double* __restrict__ qin = p.qin;
 
     // ---- issue the independent loads: gather indices, own state, element geometry
     int idx[NFN];
 #pragma unroll
-    for (int j = 0; j < NFN; ++j) idx[j] = p.vmapP[j * ld + k];
+    for (int j = 0; j < NFN; ++j) idx[j] = ld_row(p.vmapP + j * ld, k4);
     double h[Np], hu[Np], hv[Np];
 #pragma unroll
     for (int n = 0; n < Np; ++n) {
-        h[n] = qh[n * ld];
-        hu[n] = qh[plane + n * ld];
-        hv[n] = qh[2 * plane + n * ld];
+        h[n] = ld_row(qin + n * ld, k8);
+        hu[n] = ld_row(qin + plane + n * ld, k8);
+        hv[n] = ld_row(qin + 2 * plane + n * ld, k8);
     }
-    const double* __restrict__ ag = p.ageo + k;
-    const double rx = ag[0], sx = ag[ld], ry = ag[2 * ld], sy = ag[3 * ld];
+    const double* __restrict__ ag = p.ageo;
+    const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8), sy = ld_row(ag + 3 * ld, k8);
     double fnx[3], fny[3], fsc[3];
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
-        fnx[f] = ag[(4 + f) * ld];
-        fny[f] = ag[(7 + f) * ld];
-        fsc[f] = ag[(10 + f) * ld];
+        fnx[f] = ld_row(ag + (4 + f) * ld, k8);
+        fny[f] = ld_row(ag + (7 + f) * ld, k8);
+        fsc[f] = ld_row(ag + (10 + f) * ld, k8);
     }
     // Keep the loads above in one batch: without this the scheduler sinks each load next to
     // its first use to save registers and the wave pays one memory round trip per node.
     __builtin_amdgcn_sched_barrier(0);
-    // ---- neighbour ('+') traces: in flight during the volume loop
+    // ---- neighbour ('+') traces: gathers from the same planes, served by L1/L2
     double hP[NFN], huP[NFN], hvP[NFN];
 #pragma unroll
     for (int j = 0; j < NFN; ++j) {
-        const int o = idx[j] < 0 ? -(idx[j] + 1) : idx[j];
-        hP[j] = p.qin[o];
-        huP[j] = p.qin[plane + o];
-        hvP[j] = p.qin[2 * plane + o];
+        const unsigned o8 = static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u;
+        hP[j] = ld_row(qin, o8);
+        huP[j] = ld_row(qin + plane, o8);
+        hvP[j] = ld_row(qin + 2 * plane, o8);
     }
-
     __builtin_amdgcn_sched_barrier(0);
+
     const double g = p.g, halfg = 0.5 * p.g;
     double R1[Np], R2[Np], R3[Np];
 #pragma unroll
     for (int i = 0; i < Np; ++i) R1[i] = R2[i] = R3[i] = 0.0;
 
-    // ---- surface term, face by face
+    // ---- surface term, face by face: R_c[i] += Lift[i][j] * s_c[j]
 #pragma unroll
     for (int f = 0; f < 3; ++f) {
         const double nxf = fnx[f], nyf = fny[f];
@@ -97,10 +135,10 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
 #pragma unroll
         for (int n = 0; n < Nfp; ++n) {
             const int j = f * Nfp + n, m = E::fmask(f, n);
-            const double rM = 1.0 / h[m];
+            const double rM = fast_rcp(h[m]);
             uM[n] = hu[m] * rM;
             vM[n] = hv[m] * rM;
-            const double spdM = sqrt(uM[n] * uM[n] + vM[n] * vM[n]) + sqrt(g * h[m]);
+            const double spdM = fast_sqrt(uM[n] * uM[n] + vM[n] * vM[n]) + fast_sqrt(g * h[m]);
             hq[n] = hP[j];
             huq[n] = huP[j];
             hvq[n] = hvP[j];
@@ -109,10 +147,10 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
                 huq[n] = hu[m] - 2 * nxf * un;
                 hvq[n] = hv[m] - 2 * nyf * un;
             }
-            const double r = 1.0 / hq[n];
+            const double r = fast_rcp(hq[n]);
             uP[n] = huq[n] * r;
             vP[n] = hvq[n] * r;
-            const double spdP = sqrt(uP[n] * uP[n] + vP[n] * vP[n]) + sqrt(g * hq[n]);
+            const double spdP = fast_sqrt(uP[n] * uP[n] + vP[n] * vP[n]) + fast_sqrt(g * hq[n]);
             lam = fmax(lam, fmax(spdM, spdP));
         }
         const double half_fs = 0.5 * fsc[f];
@@ -139,31 +177,32 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     // ---- stage inputs that are only needed at the very end: issue now, land during the volume loop
     double old1[Np], old2[Np], old3[Np];
     if constexpr (MODE == MODE_LSERK) {
-        const double* __restrict__ rs = p.res + k;
+        const double* __restrict__ rs = p.res;
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
-            old1[i] = rs[i * ld];
-            old2[i] = rs[plane + i * ld];
-            old3[i] = rs[2 * plane + i * ld];
+            old1[i] = ld_row(rs + i * ld, k8);
+            old2[i] = ld_row(rs + plane + i * ld, k8);
+            old3[i] = ld_row(rs + 2 * plane + i * ld, k8);
         }
     } else if constexpr (MODE == MODE_COMBINE) {
-        const double* __restrict__ qb = p.qbase + k;
+        const double* __restrict__ qb = p.qbase;
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
-            old1[i] = qb[i * ld];
-            old2[i] = qb[plane + i * ld];
-            old3[i] = qb[2 * plane + i * ld];
+            old1[i] = ld_row(qb + i * ld, k8);
+            old2[i] = ld_row(qb + plane + i * ld, k8);
+            old3[i] = ld_row(qb + 2 * plane + i * ld, k8);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- volume term, one input node at a time
+    // ---- volume term, one input node at a time:
+    //      R_c[i] -= Dr[i][m] (rx F_c + ry G_c)[m] + Ds[i][m] (sx F_c + sy G_c)[m]
 #pragma unroll
     for (int m = 0; m < Np; ++m) {
         // The reciprocal is recomputed here (from h * 1.0 with a run-time 1.0, so the compiler
         // cannot reuse the surface term's value): keeping Np reciprocals live across the
-        // surface term costs more in register traffic than Np divisions.
-        const double r = 1.0 / (h[m] * p.one);
+        // surface term costs more in register traffic than Np short reciprocal sequences.
+        const double r = fast_rcp(h[m] * p.one);
         const double u = hu[m] * r, v = hv[m] * r;
         const double pr = halfg * h[m] * h[m];
         const double F2 = hu[m] * u + pr, G2 = hu[m] * v, G3 = hv[m] * v + pr;
@@ -173,46 +212,52 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
             const double dr = ops[AffineOps<N>::OFF_D + 2 * (m * Np + i)];
+            R1[i] = fma(dr, a1, R1[i]);
+            R2[i] = fma(dr, a2, R2[i]);
+            R3[i] = fma(dr, a3, R3[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
             const double ds = ops[AffineOps<N>::OFF_D + 2 * (m * Np + i) + 1];
-            R1[i] = fma(ds, b1, fma(dr, a1, R1[i]));
-            R2[i] = fma(ds, b2, fma(dr, a2, R2[i]));
-            R3[i] = fma(ds, b3, fma(dr, a3, R3[i]));
+            R1[i] = fma(ds, b1, R1[i]);
+            R2[i] = fma(ds, b2, R2[i]);
+            R3[i] = fma(ds, b3, R3[i]);
         }
     }
 
     // ---- stage update / output
     if constexpr (MODE == MODE_RHS) {
-        double* __restrict__ o = p.rhs + k;
+        double* __restrict__ o = p.rhs;
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
-            o[i * ld] = R1[i];
-            o[plane + i * ld] = R2[i];
-            o[2 * plane + i * ld] = R3[i];
+            st_row(o + i * ld, k8, R1[i]);
+            st_row(o + plane + i * ld, k8, R2[i]);
+            st_row(o + 2 * plane + i * ld, k8, R3[i]);
         }
     } else if constexpr (MODE == MODE_LSERK) {
-        double* __restrict__ rs = p.res + k;
-        double* __restrict__ o = p.qout + k;
+        double* __restrict__ rs = p.res;
+        double* __restrict__ o = p.qout;
         const double a = p.ca, b = p.cb, dt = p.cc;
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
             const double n1 = a * old1[i] + dt * R1[i];
             const double n2 = a * old2[i] + dt * R2[i];
             const double n3 = a * old3[i] + dt * R3[i];
-            rs[i * ld] = n1;
-            rs[plane + i * ld] = n2;
-            rs[2 * plane + i * ld] = n3;
-            o[i * ld] = h[i] + b * n1;
-            o[plane + i * ld] = hu[i] + b * n2;
-            o[2 * plane + i * ld] = hv[i] + b * n3;
+            st_row(rs + i * ld, k8, n1);
+            st_row(rs + plane + i * ld, k8, n2);
+            st_row(rs + 2 * plane + i * ld, k8, n3);
+            st_row(o + i * ld, k8, h[i] + b * n1);
+            st_row(o + plane + i * ld, k8, hu[i] + b * n2);
+            st_row(o + 2 * plane + i * ld, k8, hv[i] + b * n3);
         }
     } else {
-        double* __restrict__ o = p.qout + k;
+        double* __restrict__ o = p.qout;
         const double a = p.ca, b = p.cb, c = p.cc;
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
-            o[i * ld] = a * old1[i] + b * h[i] + c * R1[i];
-            o[plane + i * ld] = a * old2[i] + b * hu[i] + c * R2[i];
-            o[2 * plane + i * ld] = a * old3[i] + b * hv[i] + c * R3[i];
+            st_row(o + i * ld, k8, a * old1[i] + b * h[i] + c * R1[i]);
+            st_row(o + plane + i * ld, k8, a * old2[i] + b * hu[i] + c * R2[i]);
+            st_row(o + 2 * plane + i * ld, k8, a * old3[i] + b * hv[i] + c * R3[i]);
         }
     }
 }

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
+#   bash profiles/collect.sh r01
+# Kernel trace/stats and each PMC group run as SEPARATE rocprofv3 invocations of the same
+# bench.py command (PMC passes never combine with trace domains). Raw output goes to
+# gpurun_out/prof_<tag>_*; profiles/summarize.py turns it into profiles/<tag>_*.{csv,json}.
+set -euo pipefail
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_trace" -- $BENCH --steps 200 --warmup 20 > "$OUT/prof_${TAG}_trace.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_${TAG}_fetch" -- $BENCH --steps 20 --warmup 5 > "$OUT/prof_${TAG}_fetch.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/prof_${TAG}_write" -- $BENCH --steps 20 --warmup 5 > "$OUT/prof_${TAG}_write.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum --output-format csv -d "$OUT/prof_${TAG}_tcc" -- $BENCH --steps 20 --warmup 5 > "$OUT/prof_${TAG}_tcc.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU --output-format csv -d "$OUT/prof_${TAG}_sq" -- $BENCH --steps 20 --warmup 5 > "$OUT/prof_${TAG}_sq.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT --output-format csv -d "$OUT/prof_${TAG}_grbm" -- $BENCH --steps 20 --warmup 5 > "$OUT/prof_${TAG}_grbm.log" 2>&1
+python3 "$R/profiles/summarize.py" "$TAG" "$OUT" > "$OUT/prof_${TAG}_summary.txt" 2>&1 || true
+cat "$OUT/prof_${TAG}_summary.txt"

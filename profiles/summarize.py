@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Condenses the raw rocprofv3 CSVs written by profiles/collect.sh into the small files that
+are committed under profiles/:  <tag>_kernel_stats.csv (verbatim --stats table) and
+<tag>_pmc_summary.json (per-launch means of every counter for the stage kernel, plus the HBM
+traffic derived as MI355X_MICROARCH.md prescribes: FETCH_SIZE/WRITE_SIZE are in KiB, and on
+gfx950 FETCH_SIZE counts 64 B per 128-B request for coalesced streams, so reads = 2 x FETCH_SIZE
+-- calibrated here on scatter_rows_kernel<double>, whose byte count is known exactly).
+
+  python profiles/summarize.py <tag> <gpurun_out dir> [--into profiles/]
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def counters(path, kernel_substr):
+    agg = defaultdict(list)
+    extra = {}
+    for f in glob.glob(os.path.join(path, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                extra = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size",
+                                           "Scratch_Size", "Workgroup_Size", "Grid_Size") if k in r}
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}, extra
+
+
+def main():
+    tag, out = sys.argv[1], sys.argv[2]
+    into = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--into" else None
+    stage = "sw2d_stage"
+    summary = {"tag": tag, "kernel": None, "counters": {}, "launches_sampled": {}}
+    for group in ("fetch", "write", "tcc", "sq", "grbm"):
+        vals, n, extra = counters(os.path.join(out, f"prof_{tag}_{group}"), stage)
+        summary["counters"].update(vals)
+        summary["launches_sampled"].update(n)
+        if extra:
+            summary["resources"] = extra
+    # calibration of the FETCH_SIZE factor on a kernel whose bytes are known: the (15, K) upload
+    cal, _, cx = counters(os.path.join(out, f"prof_{tag}_fetch"), "scatter_rows_kernel<double>")
+    stats = glob.glob(os.path.join(out, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        for r in rows:
+            if stage in r["Name"]:
+                summary["kernel"] = r["Name"]
+                summary["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                           "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                                           "stddev_ns": float(r["StdDev"]), "percent_of_gpu_time": float(r["Percentage"])}
+                break
+    c = summary["counters"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        summary["hbm_traffic_per_launch"] = {
+            "fetch_size_kib": c["FETCH_SIZE"], "write_size_kib": c["WRITE_SIZE"],
+            "read_bytes": 2 * c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
+            "total_bytes": 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024,
+            "note": "reads = 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request on coalesced streams)"}
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        summary["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    print(json.dumps(summary, indent=1))
+    if into:
+        os.makedirs(into, exist_ok=True)
+        with open(os.path.join(into, f"{tag}_pmc_summary.json"), "w") as f:
+            json.dump(summary, f, indent=1)
+        if stats:
+            shutil.copyfile(stats[0], os.path.join(into, f"{tag}_kernel_stats.csv"))
+
+
+if __name__ == "__main__":
+    main()
