@@ -113,6 +113,8 @@ def run_single(args):
     solver.synchronize()
     wall = time.perf_counter() - t0
     _, eta_max = solver.computeDt(CFL)  # raises if the run blew up
+    probe_ms = solver.probeStageTraffic(20) if solver.usesAffineGeometry else None
+    triad = sw2d.streamTriadGBps(0)
 
     bytes_elem = algorithmic_bytes_per_element(ORDER)
     achieved = bytes_elem * K / (ms_per_launch * 1e-3) / 1e9
@@ -135,6 +137,7 @@ def run_single(args):
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                      "algorithmic_bytes_per_launch": bytes_elem * K, "kernel_ms": ms_per_launch,
+                     "measured_stream_triad_GBps": triad, "same_access_pattern_no_compute_ms": probe_ms,
                      "kernel": "sw2d_stage_affine_kernel<4, MODE_LSERK>" if solver.usesAffineGeometry else "sw2d_stage_kernel<4, MODE_LSERK, false>"},
     }
     if not args.no_cpu_baseline:

@@ -125,6 +125,8 @@ _SIGNATURES = {
     "bdg_sw2d_rhs_resident": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_synchronize": (c_int, [_P]),
     "bdg_sw2d_time_lserk4_stages": (c_int, [_P, c_double, c_int, POINTER(c_float)]),
+    "bdg_probe_stream_triad": (c_int, [c_int, c_size_t, c_int, POINTER(c_double)]),
+    "bdg_sw2d_probe_stage_traffic": (c_int, [_P, c_int, POINTER(c_float)]),
     "bdg_sw2d_uses_affine_geometry": (c_int, [_P]),
     "bdg_sw2d_device_bytes": (c_size_t, [_P]),
     "bdg_sw2d_stream": (c_void_p, [_P]),

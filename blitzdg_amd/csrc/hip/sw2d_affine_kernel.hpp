@@ -263,3 +263,209 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
 }
 
 } // namespace bdg_dev
+
+namespace bdg_dev {
+
+// ---------------------------------------------------------------------------------------------
+// Streamed variant: the 3*Np accumulators are the only long-lived registers; the state is read
+// three times (volume term, face traces, stage update) with the 2nd and 3rd read served by L2.
+// The register budget (WAVES per SIMD as launch bound) lets two or three waves share a SIMD: one
+// wave alone can issue a vector instruction only every other slot, and the partner wave also
+// hides the per-face gather latency.
+template <int N, int MODE, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void sw2d_stage_affine_stream_kernel(const StageParams p) {
+    using E = Elem<N>;
+    constexpr int Np = E::Np, Nfp = E::Nfp;
+
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const unsigned tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const unsigned k = static_cast<unsigned>(p.kbegin) + tile * blockDim.x + threadIdx.x;
+    if (k >= static_cast<unsigned>(p.kend)) return;
+    const unsigned k8 = k * 8u, k4 = k * 4u;
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
+    const double* __restrict__ ops = p.opsAffine;
+    const double* __restrict__ qin = p.qin;
+    const double* __restrict__ ag = p.ageo;
+    const double g = p.g, halfg = 0.5 * p.g;
+
+    double R1[Np], R2[Np], R3[Np];
+#pragma unroll
+    for (int i = 0; i < Np; ++i) R1[i] = R2[i] = R3[i] = 0.0;
+
+    // ---- volume term: stream the own state in chunks of VCH nodes, next chunk in flight
+    {
+        const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
+                     sy = ld_row(ag + 3 * ld, k8);
+        constexpr int VCH = 5, NCH = (Np + VCH - 1) / VCH;
+        double hc[2][VCH], huc[2][VCH], hvc[2][VCH];
+#pragma unroll
+        for (int t = 0; t < VCH; ++t)
+            if (t < Np) {
+                hc[0][t] = ld_row(qin + t * ld, k8);
+                huc[0][t] = ld_row(qin + plane + t * ld, k8);
+                hvc[0][t] = ld_row(qin + 2 * plane + t * ld, k8);
+            }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int cur = c & 1, nxt = cur ^ 1;
+#pragma unroll
+            for (int t = 0; t < VCH; ++t) {
+                const int m = (c + 1) * VCH + t;
+                if (m < Np) {
+                    hc[nxt][t] = ld_row(qin + m * ld, k8);
+                    huc[nxt][t] = ld_row(qin + plane + m * ld, k8);
+                    hvc[nxt][t] = ld_row(qin + 2 * plane + m * ld, k8);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < VCH; ++t) {
+                const int m = c * VCH + t;
+                if (m < Np) {
+                    const double h = hc[cur][t], hu = huc[cur][t], hv = hvc[cur][t];
+                    const double r = fast_rcp(h);
+                    const double u = hu * r, v = hv * r;
+                    const double pr = halfg * h * h;
+                    const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
+                    const double a1 = -(rx * hu + ry * hv), b1 = -(sx * hu + sy * hv);
+                    const double a2 = -(rx * F2 + ry * G2), b2 = -(sx * F2 + sy * G2);
+                    const double a3 = -(rx * G2 + ry * G3), b3 = -(sx * G2 + sy * G3);
+#pragma unroll
+                    for (int i = 0; i < Np; ++i) {
+                        const double dr = ops[AffineOps<N>::OFF_D + 2 * (m * Np + i)];
+                        R1[i] = fma(dr, a1, R1[i]);
+                        R2[i] = fma(dr, a2, R2[i]);
+                        R3[i] = fma(dr, a3, R3[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < Np; ++i) {
+                        const double ds = ops[AffineOps<N>::OFF_D + 2 * (m * Np + i) + 1];
+                        R1[i] = fma(ds, b1, R1[i]);
+                        R2[i] = fma(ds, b2, R2[i]);
+                        R3[i] = fma(ds, b3, R3[i]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- surface term, face by face; '-' and '+' traces are (re)read per face
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const double nxf = ld_row(ag + (4 + f) * ld, k8), nyf = ld_row(ag + (7 + f) * ld, k8);
+        const double half_fs = 0.5 * ld_row(ag + (10 + f) * ld, k8);
+        int idx[Nfp];
+        double hM[Nfp], huM[Nfp], hvM[Nfp], hq[Nfp], huq[Nfp], hvq[Nfp];
+#pragma unroll
+        for (int n = 0; n < Nfp; ++n) idx[n] = ld_row(p.vmapP + (f * Nfp + n) * ld, k4);
+#pragma unroll
+        for (int n = 0; n < Nfp; ++n) {
+            const int m = E::fmask(f, n);
+            hM[n] = ld_row(qin + m * ld, k8);
+            huM[n] = ld_row(qin + plane + m * ld, k8);
+            hvM[n] = ld_row(qin + 2 * plane + m * ld, k8);
+        }
+#pragma unroll
+        for (int n = 0; n < Nfp; ++n) {
+            const unsigned o8 = static_cast<unsigned>(idx[n] < 0 ? -(idx[n] + 1) : idx[n]) * 8u;
+            hq[n] = ld_row(qin, o8);
+            huq[n] = ld_row(qin + plane, o8);
+            hvq[n] = ld_row(qin + 2 * plane, o8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        double lam = 0.0;
+#pragma unroll
+        for (int n = 0; n < Nfp; ++n) {
+            if (idx[n] < 0) { // reflective wall: no normal flow
+                const double un = huM[n] * nxf + hvM[n] * nyf;
+                huq[n] = huM[n] - 2 * nxf * un;
+                hvq[n] = hvM[n] - 2 * nyf * un;
+            }
+            const double rM = fast_rcp(hM[n]), rP = fast_rcp(hq[n]);
+            const double uM = huM[n] * rM, vM = hvM[n] * rM, uP = huq[n] * rP, vP = hvq[n] * rP;
+            const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM[n]);
+            const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq[n]);
+            lam = fmax(lam, fmax(spdM, spdP));
+        }
+#pragma unroll
+        for (int n = 0; n < Nfp; ++n) {
+            const int j = f * Nfp + n;
+            // velocities are recomputed rather than kept across the two passes (registers)
+            const double rM = fast_rcp(hM[n] * p.one), rP = fast_rcp(hq[n] * p.one);
+            const double uM = huM[n] * rM, vM = hvM[n] * rM, uP = huq[n] * rP, vP = hvq[n] * rP;
+            const double prM = halfg * hM[n] * hM[n], prP = halfg * hq[n] * hq[n];
+            const double F2M = huM[n] * uM + prM, G2M = huM[n] * vM, G3M = hvM[n] * vM + prM;
+            const double F2P = huq[n] * uP + prP, G2P = huq[n] * vP, G3P = hvq[n] * vP + prP;
+            const double dh = hM[n] - hq[n], dhu = huM[n] - huq[n], dhv = hvM[n] - hvq[n];
+            const double s1 = half_fs * (dhu * nxf + dhv * nyf - lam * dh);
+            const double s2 = half_fs * ((F2M - F2P) * nxf + (G2M - G2P) * nyf - lam * dhu);
+            const double s3 = half_fs * ((G2M - G2P) * nxf + (G3M - G3P) * nyf - lam * dhv);
+#pragma unroll
+            for (int i = 0; i < Np; ++i) {
+                const double lj = ops[AffineOps<N>::OFF_LIFT + j * Np + i];
+                R1[i] = fma(lj, s1, R1[i]);
+                R2[i] = fma(lj, s2, R2[i]);
+                R3[i] = fma(lj, s3, R3[i]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- stage update / output, a few nodes at a time
+    if constexpr (MODE == MODE_RHS) {
+        double* __restrict__ o = p.rhs;
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            st_row(o + i * ld, k8, R1[i]);
+            st_row(o + plane + i * ld, k8, R2[i]);
+            st_row(o + 2 * plane + i * ld, k8, R3[i]);
+        }
+    } else {
+        constexpr int CH = 5; // nodes per batch of loads
+        const double* __restrict__ base2 = (MODE == MODE_LSERK) ? p.res : p.qbase;
+        double* __restrict__ o = p.qout;
+        const double a = p.ca, b = p.cb, c = p.cc;
+#pragma unroll
+        for (int i0 = 0; i0 < Np; i0 += CH) {
+            double q1[CH], q2[CH], q3[CH], o1[CH], o2[CH], o3[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int i = i0 + t;
+                if (i < Np) {
+                    q1[t] = ld_row(qin + i * ld, k8);
+                    q2[t] = ld_row(qin + plane + i * ld, k8);
+                    q3[t] = ld_row(qin + 2 * plane + i * ld, k8);
+                    o1[t] = ld_row(base2 + i * ld, k8);
+                    o2[t] = ld_row(base2 + plane + i * ld, k8);
+                    o3[t] = ld_row(base2 + 2 * plane + i * ld, k8);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < CH; ++t) {
+                const int i = i0 + t;
+                if (i < Np) {
+                    if constexpr (MODE == MODE_LSERK) {
+                        const double n1 = a * o1[t] + c * R1[i], n2 = a * o2[t] + c * R2[i], n3 = a * o3[t] + c * R3[i];
+                        st_row(p.res + i * ld, k8, n1);
+                        st_row(p.res + plane + i * ld, k8, n2);
+                        st_row(p.res + 2 * plane + i * ld, k8, n3);
+                        st_row(o + i * ld, k8, q1[t] + b * n1);
+                        st_row(o + plane + i * ld, k8, q2[t] + b * n2);
+                        st_row(o + 2 * plane + i * ld, k8, q3[t] + b * n3);
+                    } else {
+                        st_row(o + i * ld, k8, a * o1[t] + b * q1[t] + c * R1[i]);
+                        st_row(o + plane + i * ld, k8, a * o2[t] + b * q2[t] + c * R2[i]);
+                        st_row(o + 2 * plane + i * ld, k8, a * o3[t] + b * q3[t] + c * R3[i]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+} // namespace bdg_dev

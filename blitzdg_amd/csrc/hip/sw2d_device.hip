@@ -19,6 +19,7 @@
 #include <rccl/rccl.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <queue>
@@ -116,6 +117,38 @@ __global__ void halo_unpack_kernel(double* __restrict__ q, const double* __restr
     q[r * ld + first + i] = buf[i * rows + r];
 }
 
+// ---- bandwidth probes (measurement aids, not part of the solver)
+// STREAM triad a = b + s*c on 16-byte lanes: the practical HBM roof of this device.
+__global__ __launch_bounds__(256) void triad_kernel(double2* __restrict__ a, const double2* __restrict__ b,
+                                                    const double2* __restrict__ c, double s, size_t n2) {
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        const double2 x = b[i], y = c[i];
+        a[i] = make_double2(x.x + s * y.x, x.y + s * y.y);
+    }
+}
+
+// Same rows, same 8-byte-per-lane accesses and same read/write mix as one fused LSERK stage of
+// the affine kernel (reads: state 3Np rows, residual 3Np rows, 13 geometry rows, 3Nfp index rows;
+// writes: residual and state, 6Np rows), with no gathers and almost no arithmetic: the time of
+// this launch is the memory-system floor for the stage kernel's own access pattern.
+__global__ __launch_bounds__(256) void stage_traffic_probe_kernel(const double* __restrict__ qin, double* __restrict__ qout,
+                                                                 double* __restrict__ res, const double* __restrict__ ageo,
+                                                                 const int* __restrict__ vmapP, int rows, int idxRows,
+                                                                 long long ld, int K) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= static_cast<unsigned>(K)) return;
+    double acc = 0.0;
+    for (int r = 0; r < 13; ++r) acc += ageo[r * ld + k];
+    for (int r = 0; r < idxRows; ++r) acc += vmapP[r * ld + k];
+    for (int r = 0; r < rows; ++r) {
+        const double q = qin[r * ld + k], o = res[r * ld + k];
+        const double n = 0.5 * o + 1e-300 * (q + acc);
+        res[r * ld + k] = n;
+        qout[r * ld + k] = q + 1e-300 * n;
+    }
+}
+
 } // namespace bdg_dev
 
 using bdg_detail::arg_error;
@@ -207,6 +240,7 @@ struct bdg_sw2d {
     DevBuf<double> qA, qB, res, aux, geo, fgeo, ops, Hbuf, stage, partials, red2;
     DevBuf<double> ageo, opsAffine, opsAffineFiltered; // affine-geometry fast path
     bool affine = false;
+    int affineVariant = 0; // 0: register-resident state; 2/3: streamed state at 2/3 waves per SIMD
     DevBuf<int> vmapP, perm, istage, sendSlots;
     int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
     // native halo exchange (RCCL over xGMI): one send and one receive range per neighbour rank
@@ -277,7 +311,7 @@ struct bdg_sw2d {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
         if (affine) {
             p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
-            hipCheck(kt->stageAffine(mode, p, stream), what);
+            hipCheck(kt->stageAffine(mode, affineVariant, p, stream), what);
         } else {
             hipCheck(kt->stage(mode, filter, p, stream), what);
         }
@@ -583,6 +617,10 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
 
     // ---- affine fast path: one metric value per element, one normal/scale per face
     s->affine = !(d.flags & BDG_SW2D_NODAL_GEOMETRY) && geometryIsAffine(d, Np, Nfp, K);
+    if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
+        const int v = std::atoi(e);
+        if (v == 0 || v == 2 || v == 3) s->affineVariant = v;
+    }
     if (s->affine) {
         s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);
         hipCheck(hipMemsetAsync(s->ageo.p, 0, s->ageo.n * sizeof(double), s->stream), "hipMemset");
@@ -1000,6 +1038,60 @@ int bdg_sw2d_barrier(bdg_sw2d* s) {
         if (s->commStream) hipCheck(hipStreamSynchronize(s->commStream), "hipStreamSynchronize");
         (void)s->allReduceScalar(0.0, true); // every rank arrives before anyone leaves
         hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+    });
+}
+
+int bdg_probe_stream_triad(int device, size_t bytes_per_array, int repeats, double* gbps) {
+    return guard([&] {
+        if (!gbps || repeats < 1 || bytes_per_array < (1u << 20)) throw arg_error("bdg_probe_stream_triad: bad argument");
+        hipCheck(hipSetDevice(device), "hipSetDevice");
+        const size_t n2 = bytes_per_array / sizeof(double2);
+        size_t total = 0;
+        DevBuf<double> a, b, c;
+        a.alloc(2 * n2, total); b.alloc(2 * n2, total); c.alloc(2 * n2, total);
+        hipCheck(hipMemset(a.p, 0, 2 * n2 * sizeof(double)), "hipMemset");
+        hipCheck(hipMemset(b.p, 0, 2 * n2 * sizeof(double)), "hipMemset");
+        hipCheck(hipMemset(c.p, 0, 2 * n2 * sizeof(double)), "hipMemset");
+        hipEvent_t e0, e1;
+        hipCheck(hipEventCreate(&e0), "hipEventCreate");
+        hipCheck(hipEventCreate(&e1), "hipEventCreate");
+        auto launch = [&] {
+            hipLaunchKernelGGL(bdg_dev::triad_kernel, dim3(256 * 8), dim3(256), 0, nullptr, reinterpret_cast<double2*>(a.p),
+                               reinterpret_cast<const double2*>(b.p), reinterpret_cast<const double2*>(c.p), 0.5, n2);
+        };
+        launch();
+        hipCheck(hipEventRecord(e0, nullptr), "hipEventRecord");
+        for (int i = 0; i < repeats; ++i) launch();
+        hipCheck(hipEventRecord(e1, nullptr), "hipEventRecord");
+        hipCheck(hipEventSynchronize(e1), "hipEventSynchronize");
+        float ms = 0.f;
+        hipCheck(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *gbps = 3.0 * static_cast<double>(n2) * sizeof(double2) * repeats / (ms * 1e-3) / 1e9;
+    });
+}
+
+int bdg_sw2d_probe_stage_traffic(bdg_sw2d* s, int repeats, float* ms_per_launch) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_probe_stage_traffic");
+        if (!ms_per_launch || repeats < 1) throw arg_error("bdg_sw2d_probe_stage_traffic: bad argument");
+        if (!s->affine) throw arg_error("bdg_sw2d_probe_stage_traffic: affine geometry only");
+        s->use();
+        const unsigned grid = static_cast<unsigned>((s->K + 255) / 256);
+        auto launch = [&] {
+            // aux / qalt are scratch here: the resident state is not modified
+            hipLaunchKernelGGL(bdg_dev::stage_traffic_probe_kernel, dim3(grid), dim3(256), 0, s->stream, s->qcur, s->qalt,
+                               s->aux.p, s->ageo.p, s->vmapP.p, 3 * s->Np, s->NFN, s->ld, s->K);
+        };
+        launch();
+        hipCheck(hipEventRecord(s->ev0, s->stream), "hipEventRecord");
+        for (int i = 0; i < repeats; ++i) launch();
+        hipCheck(hipEventRecord(s->ev1, s->stream), "hipEventRecord");
+        hipCheck(hipEventSynchronize(s->ev1), "hipEventSynchronize");
+        float ms = 0.f;
+        hipCheck(hipEventElapsedTime(&ms, s->ev0, s->ev1), "hipEventElapsedTime");
+        *ms_per_launch = ms / repeats;
     });
 }
 

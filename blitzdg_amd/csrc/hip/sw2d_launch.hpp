@@ -13,7 +13,7 @@ struct KernelTable {
     hipError_t (*stage)(int mode, bool filter, const StageParams& p, hipStream_t stream);
     // affine-geometry fast path (no FILTER template: the filter is folded into the operators)
     int affineOpsDoubles;
-    hipError_t (*stageAffine)(int mode, const StageParams& p, hipStream_t stream);
+    hipError_t (*stageAffine)(int mode, int variant, const StageParams& p, hipStream_t stream);
     // per-block partial maxima (2 doubles per block of 256 elements)
     hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
                      double* partials, hipStream_t stream);

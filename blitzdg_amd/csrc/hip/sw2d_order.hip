@@ -37,7 +37,32 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t stageAffine(int mode, const StageParams& p, hipStream_t stream) {
+template <int MODE, int WAVES>
+hipError_t launchStream(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sw2d_stage_affine_stream_kernel<kN, MODE, WAVES>), dim3(grid), dim3(kBlock), 0, stream, p);
+    return hipGetLastError();
+}
+
+// variant: 0 = register-resident state (1 wave/SIMD), 2 / 3 = streamed state at 2 / 3 waves per SIMD
+hipError_t stageAffine(int mode, int variant, const StageParams& p, hipStream_t stream) {
+    if (variant == 2) {
+        switch (mode) {
+        case MODE_RHS: return launchStream<MODE_RHS, 2>(p, stream);
+        case MODE_LSERK: return launchStream<MODE_LSERK, 2>(p, stream);
+        case MODE_COMBINE: return launchStream<MODE_COMBINE, 2>(p, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
+    if (variant == 3) {
+        switch (mode) {
+        case MODE_RHS: return launchStream<MODE_RHS, 3>(p, stream);
+        case MODE_LSERK: return launchStream<MODE_LSERK, 3>(p, stream);
+        case MODE_COMBINE: return launchStream<MODE_COMBINE, 3>(p, stream);
+        default: return hipErrorInvalidValue;
+        }
+    }
     switch (mode) {
     case MODE_RHS: return launchAffine<MODE_RHS>(p, stream);
     case MODE_LSERK: return launchAffine<MODE_LSERK>(p, stream);

@@ -125,6 +125,12 @@ class Sw2dSolver:
         check(lib.bdg_sw2d_time_lserk4_stages(self._h, float(dt), int(nstages), byref(ms)))
         return ms.value
 
+    def probeStageTraffic(self, repeats=20):
+        """Milliseconds of a launch with the stage kernel's memory accesses but no gathers / arithmetic."""
+        ms = c_float()
+        check(lib.bdg_sw2d_probe_stage_traffic(self._h, int(repeats), byref(ms)))
+        return ms.value
+
     @property
     def usesAffineGeometry(self):
         return bool(lib.bdg_sw2d_uses_affine_geometry(self._h))
@@ -132,6 +138,13 @@ class Sw2dSolver:
     @property
     def deviceBytes(self):
         return lib.bdg_sw2d_device_bytes(self._h)
+
+
+def streamTriadGBps(device=0, bytesPerArray=1 << 30, repeats=10):
+    """Measured STREAM-triad bandwidth of the device in GB/s (the practical HBM roof)."""
+    out = c_double()
+    check(lib.bdg_probe_stream_triad(int(device), int(bytesPerArray), int(repeats), byref(out)))
+    return out.value
 
 
 _solver_cache = weakref.WeakKeyDictionary()

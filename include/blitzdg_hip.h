@@ -230,6 +230,12 @@ int bdg_sw2d_synchronize(bdg_sw2d* s);
  * returns the average device time per stage-kernel launch in milliseconds. */
 int bdg_sw2d_time_lserk4_stages(bdg_sw2d* s, double dt, int num_stages, float* ms_per_launch);
 /* Bytes of HBM the solver holds; algorithmic bytes per element per fused stage. */
+/* Measurement aids. bdg_probe_stream_triad: STREAM triad (a = b + s*c, 16 B per lane) over three
+ * arrays of bytes_per_array each; returns GB/s -- the practical HBM roof of the device.
+ * bdg_sw2d_probe_stage_traffic: a launch with the stage kernel's own row accesses and read/write
+ * mix but no gathers and no arithmetic; its time is the memory-system floor for that pattern. */
+int bdg_probe_stream_triad(int device, size_t bytes_per_array, int repeats, double* gbps);
+int bdg_sw2d_probe_stage_traffic(bdg_sw2d* s, int repeats, float* ms_per_launch);
 /* 1 if the solver runs the affine-geometry kernels, 0 for the per-node-geometry kernels. */
 int bdg_sw2d_uses_affine_geometry(const bdg_sw2d* s);
 size_t bdg_sw2d_device_bytes(const bdg_sw2d* s);
