@@ -240,3 +240,18 @@ def test_advec1d_cpu_config():
     e100, steps100 = dg.advec1dRun(N=4, K=100, finalTime=20.0)  # BASELINE.json configs[0]
     assert steps30 == 87 and steps100 == 290
     assert e30 < 1e-4 and e100 < 4.6e-5
+
+
+def test_cpp_driver_advec1d_prints_the_reference_error_line():
+    """bin/advec1d (examples/advec1d.cpp over include/blitzdg/Advec1d.hpp): BASELINE configs[0]."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "advec1d")
+    if not os.path.exists(exe):
+        pytest.skip("bin/advec1d not built (run __graft_entry__.build())")
+    out = subprocess.run([exe, "4", "100", "20"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    err = float(re.search(r"Error: ([-+.\deE]+)", out.stdout).group(1))
+    ref, _ = dg.advec1dRun(N=4, K=100, finalTime=20.0)
+    assert abs(err - ref) / ref < 1e-5
