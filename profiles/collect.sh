@@ -9,6 +9,7 @@ TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
+rm -rf "$OUT"/prof_${TAG}_*   # stale CSVs from earlier collections would be averaged in
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $R/bench.py --no-cpu-baseline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_trace" -- $BENCH --steps 200 --warmup 20 > "$OUT/prof_${TAG}_trace.log" 2>&1
