@@ -48,6 +48,21 @@ def actual_bytes_per_element(order, affine):
     return 3 * np_ * 8 * 4 + geo + 3 * nfp * 4
 
 
+def committed_traffic():
+    """HBM bytes per stage-kernel launch from the PMC passes of this same command
+    (profiles/collect.sh -> profiles/<tag>_pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in
+    separate rocprofv3 --pmc runs, reads = 2 x FETCH_SIZE on gfx950). None if no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d["hbm_traffic_per_launch"]["total_bytes"], os.path.basename(files[-1])
+    except (KeyError, ValueError, OSError):
+        return None, None
+
+
 def initial_state(x, y):
     h = 10.0 + np.exp(-10 * x * x - 10 * y * y)
     z = np.zeros_like(h)
@@ -118,6 +133,7 @@ def run_single(args):
 
     bytes_elem = algorithmic_bytes_per_element(ORDER)
     achieved = bytes_elem * K / (ms_per_launch * 1e-3) / 1e9
+    traffic, traffic_src = committed_traffic()
     line = {
         "metric": "element-DOF updates/sec (sw2d RHS + LSERK4 stage, N=4, 1M tris)",
         "value": Np * K * args.steps / wall,
@@ -135,7 +151,7 @@ def run_single(args):
                    "dt": dt, "eta_max_after": eta_max, "setup_seconds": round(t_setup, 2),
                    "device_bytes": solver.deviceBytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_elem * K, "kernel_ms": ms_per_launch,
                      "measured_stream_triad_GBps": triad, "same_access_pattern_no_compute_ms": probe_ms,
                      "kernel": "sw2d_stage_affine_kernel<4, MODE_LSERK>" if solver.usesAffineGeometry else "sw2d_stage_kernel<4, MODE_LSERK, false>"},
