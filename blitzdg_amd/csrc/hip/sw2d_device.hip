@@ -34,6 +34,8 @@ const KernelTable* kernel_table_order3();
 const KernelTable* kernel_table_order4();
 const KernelTable* kernel_table_order5();
 const KernelTable* kernel_table_order6();
+const KernelTable* kernel_table_order7();
+const KernelTable* kernel_table_order8();
 
 const KernelTable* kernel_table(int order) {
     switch (order) {
@@ -43,6 +45,8 @@ const KernelTable* kernel_table(int order) {
     case 4: return kernel_table_order4();
     case 5: return kernel_table_order5();
     case 6: return kernel_table_order6();
+    case 7: return kernel_table_order7();
+    case 8: return kernel_table_order8();
     default: return nullptr;
     }
 }
@@ -251,6 +255,7 @@ struct bdg_sw2d {
     hipStream_t commStream = nullptr;
     hipEvent_t evPacked = nullptr, evExchanged = nullptr;
     DevBuf<double> sendBuf, recvBuf, scalarBuf;
+    double* fscaleNodal = nullptr; // (NFN, ld) per-node Fscale plane (time-step reduction)
     double* qcur = nullptr;  // current state
     double* qalt = nullptr;  // the other buffer
     long long stageCount = 0; // LSERK stage counter (stage index = count % 5)
@@ -424,7 +429,7 @@ struct bdg_sw2d {
     // Returns {max |Fscale|*spd, max |eta|}; NaN if any entry is NaN.
     void reduceDt(double out[2]) {
         const int nblocks = (numOwned + 255) / 256;
-        hipCheck(kt->dt(qcur, fgeo.p + 2 * static_cast<size_t>(NFN) * ld, hasH ? Hbuf.p : nullptr, ld, numOwned, g, partials.p,
+        hipCheck(kt->dt(qcur, fscaleNodal, hasH ? Hbuf.p : nullptr, ld, numOwned, g, partials.p,
                         stream), "sw2d_dt_kernel");
         hipLaunchKernelGGL(bdg_dev::sw2d_reduce_kernel, dim3(1), dim3(256), 0, stream, partials.p, nblocks, red2.p);
         hipCheck(hipGetLastError(), "sw2d_reduce_kernel");
@@ -560,6 +565,9 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
             throw arg_error("bdg_sw2d_create: wall-node index out of range");
 
     if (d.flags & BDG_SW2D_REORDER) s->permHost = bfsOrder(d.vmapP, K, Np, Nfp);
+    s->affine = !(d.flags & BDG_SW2D_NODAL_GEOMETRY) && geometryIsAffine(d, Np, Nfp, K);
+    if (!s->affine && kt->ldsDoubles == 0)
+        throw arg_error("bdg_sw2d_create: orders above 6 are implemented for straight-sided (affine) geometry only");
 
     s->use();
     hipCheck(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -571,10 +579,19 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->qB.alloc(plane3, s->bytes);
     s->res.alloc(plane3, s->bytes);
     s->aux.alloc(plane3, s->bytes);
-    s->geo.alloc(4 * s->planeSize(), s->bytes);
-    s->fgeo.alloc(3 * static_cast<size_t>(NFN) * ld, s->bytes);
+    // Per-node geometry planes and the LDS operator image belong to the nodal kernels; the affine
+    // path keeps 13 values per element (below) plus the per-node Fscale plane, which only the
+    // time-step reduction reads (so that dt stays bit-identical to the reference formula).
+    const size_t fplane = static_cast<size_t>(NFN) * ld;
+    if (!s->affine) {
+        s->geo.alloc(4 * s->planeSize(), s->bytes);
+        s->fgeo.alloc(3 * fplane, s->bytes);
+        s->ops.alloc(kt->ldsDoubles, s->bytes);
+    } else {
+        s->fgeo.alloc(fplane, s->bytes);
+    }
+    s->fscaleNodal = s->affine ? s->fgeo.p : s->fgeo.p + 2 * fplane;
     s->vmapP.alloc(static_cast<size_t>(NFN) * ld, s->bytes);
-    s->ops.alloc(kt->ldsDoubles, s->bytes);
     s->stage.alloc(static_cast<size_t>(std::max(Np, NFN)) * K, s->bytes);
     s->istage.alloc(static_cast<size_t>(NFN) * K, s->bytes);
     s->partials.alloc(2 * static_cast<size_t>((K + 255) / 256), s->bytes);
@@ -584,42 +601,42 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
         hipCheck(hipMemcpy(s->perm.p, s->permHost.data(), sizeof(int) * K, hipMemcpyHostToDevice), "perm upload");
     }
     for (auto* b : {&s->qA, &s->qB, &s->res, &s->aux, &s->geo, &s->fgeo})
-        hipCheck(hipMemsetAsync(b->p, 0, b->n * sizeof(double), s->stream), "hipMemset");
+        if (b->p) hipCheck(hipMemsetAsync(b->p, 0, b->n * sizeof(double), s->stream), "hipMemset");
     hipCheck(hipMemsetAsync(s->vmapP.p, 0, s->vmapP.n * sizeof(int), s->stream), "hipMemset");
     s->qcur = s->qA.p;
     s->qalt = s->qB.p;
 
-    // ---- operator image: [Dr,Ds interleaved | Lift | Filter]
-    std::vector<double> img(kt->ldsDoubles, 0.0);
-    for (int i = 0; i < Np * Np; ++i) {
-        img[2 * i] = d.Dr[i];
-        img[2 * i + 1] = d.Ds[i];
+    s->hasFilter = d.Filter != nullptr;
+    if (!s->affine) {
+        // ---- operator image for the nodal kernels: [Dr,Ds interleaved | Lift | Filter]
+        std::vector<double> img(kt->ldsDoubles, 0.0);
+        for (int i = 0; i < Np * Np; ++i) {
+            img[2 * i] = d.Dr[i];
+            img[2 * i + 1] = d.Ds[i];
+        }
+        std::copy(d.Lift, d.Lift + static_cast<size_t>(Np) * NFN, img.begin() + 2 * Np * Np);
+        if (d.Filter) std::copy(d.Filter, d.Filter + static_cast<size_t>(Np) * Np, img.begin() + 2 * Np * Np + Np * NFN);
+        hipCheck(hipMemcpyAsync(s->ops.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, s->stream),
+                 "ops upload");
+        hipCheck(hipStreamSynchronize(s->stream), "ops sync");
     }
-    std::copy(d.Lift, d.Lift + static_cast<size_t>(Np) * NFN, img.begin() + 2 * Np * Np);
-    if (d.Filter) {
-        std::copy(d.Filter, d.Filter + static_cast<size_t>(Np) * Np, img.begin() + 2 * Np * Np + Np * NFN);
-        s->hasFilter = true;
-    }
-    hipCheck(hipMemcpyAsync(s->ops.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, s->stream),
-             "ops upload");
-    hipCheck(hipStreamSynchronize(s->stream), "ops sync");
 
     // ---- geometry planes
-    const size_t pl = s->planeSize();
-    s->uploadRows(d.rx, s->geo.p, Np);
-    s->uploadRows(d.sx, s->geo.p + pl, Np);
-    s->uploadRows(d.ry, s->geo.p + 2 * pl, Np);
-    s->uploadRows(d.sy, s->geo.p + 3 * pl, Np);
-    const size_t fpl = static_cast<size_t>(NFN) * ld;
-    s->uploadRows(d.nx, s->fgeo.p, NFN);
-    s->uploadRows(d.ny, s->fgeo.p + fpl, NFN);
-    s->uploadRows(d.Fscale, s->fgeo.p + 2 * fpl, NFN);
+    if (!s->affine) {
+        const size_t pl = s->planeSize();
+        s->uploadRows(d.rx, s->geo.p, Np);
+        s->uploadRows(d.sx, s->geo.p + pl, Np);
+        s->uploadRows(d.ry, s->geo.p + 2 * pl, Np);
+        s->uploadRows(d.sy, s->geo.p + 3 * pl, Np);
+        s->uploadRows(d.nx, s->fgeo.p, NFN);
+        s->uploadRows(d.ny, s->fgeo.p + fplane, NFN);
+    }
+    s->uploadRows(d.Fscale, s->fscaleNodal, NFN);
 
     // ---- affine fast path: one metric value per element, one normal/scale per face
-    s->affine = !(d.flags & BDG_SW2D_NODAL_GEOMETRY) && geometryIsAffine(d, Np, Nfp, K);
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v == 0 || v == 2 || v == 3) s->affineVariant = v;
+        if (v >= 0 && v <= 3) s->affineVariant = v;
     }
     if (s->affine) {
         s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);

@@ -10,13 +10,35 @@ namespace {
 
 constexpr int kN = BDG_ORDER;
 constexpr int kBlock = 256;
+// Orders above this use the field-split kernels only (3*Np accumulators exceed the VGPR file).
+constexpr bool kHighOrder = BDG_ORDER > 6;
+
+template <int MODE>
+hipError_t launchFieldSplit(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
+    hipLaunchKernelGGL((sw2d_stage_affine_fieldsplit_kernel<kN, MODE>), dim3(grid), dim3(192), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t stageFieldSplit(int mode, const StageParams& p, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchFieldSplit<MODE_RHS>(p, stream);
+    case MODE_LSERK: return launchFieldSplit<MODE_LSERK>(p, stream);
+    case MODE_COMBINE: return launchFieldSplit<MODE_COMBINE>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
 
 template <int MODE, bool FILTER>
 hipError_t launchStage(const StageParams& p, hipStream_t stream) {
+    if constexpr (kHighOrder) return hipErrorNotSupported;
+    else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((sw2d_stage_kernel<kN, MODE, FILTER>), dim3(grid), dim3(kBlock), 0, stream, p);
     return hipGetLastError();
+    }
 }
 
 hipError_t stage(int mode, bool filter, const StageParams& p, hipStream_t stream) {
@@ -31,22 +53,29 @@ hipError_t stage(int mode, bool filter, const StageParams& p, hipStream_t stream
 
 template <int MODE>
 hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
+    if constexpr (kHighOrder) return stageFieldSplit(MODE, p, stream);
+    else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kBlock), 0, stream, p);
     return hipGetLastError();
+    }
 }
 
 template <int MODE, int WAVES>
 hipError_t launchStream(const StageParams& p, hipStream_t stream) {
+    if constexpr (kHighOrder) return stageFieldSplit(MODE, p, stream);
+    else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
     hipLaunchKernelGGL((sw2d_stage_affine_stream_kernel<kN, MODE, WAVES>), dim3(grid), dim3(kBlock), 0, stream, p);
     return hipGetLastError();
+    }
 }
 
 // variant: 0 = register-resident state (1 wave/SIMD), 2 / 3 = streamed state at 2 / 3 waves per SIMD
 hipError_t stageAffine(int mode, int variant, const StageParams& p, hipStream_t stream) {
+    if (variant == 1) return stageFieldSplit(mode, p, stream);
     if (variant == 2) {
         switch (mode) {
         case MODE_RHS: return launchStream<MODE_RHS, 2>(p, stream);
@@ -87,7 +116,7 @@ int fmaskOf(int f, int n) { return Elem<kN>::fmask(f, n); }
 // A host function (not a namespace-scope constant, which hipcc would also emit for
 // the device and then fail to resolve the host function pointers in).
 const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
-    static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, Elem<kN>::LDS_DOUBLES, &stage,
+    static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, &dt, &fmaskOf};
     return &table;
 }

@@ -154,7 +154,7 @@ typedef struct bdg_sw2d_desc {
     int flags;          /* BDG_SW2D_* bits                                            */
 } bdg_sw2d_desc;
 
-#define BDG_SW2D_MAX_ORDER 6
+#define BDG_SW2D_MAX_ORDER 8 /* 7 and 8: straight-sided (affine) geometry only */
 #define BDG_SW2D_REORDER 1u /* renumber elements internally for gather locality (results are
                                returned in the caller's numbering either way)         */
 #define BDG_SW2D_NODAL_GEOMETRY 2u /* always read rx..sy, nx, ny, Fscale per node (general path).
