@@ -111,11 +111,11 @@ def run_single(args):
 
     t_setup = time.perf_counter()
     mesh = dg.MeshManager()
-    mesh.buildBoxMesh(NX, NY)
+    mesh.buildBoxMesh(NX, NY, shuffleSeed=args.shuffle_seed)
     nodes = dg.TriangleNodesProvisioner(ORDER, mesh)
     ctx = nodes.dgContext()
     K, Np = ctx.numElements, ctx.numLocalPoints
-    solver = sw2d.Sw2dSolver(nodes=nodes, g=G, device=0)
+    solver = sw2d.Sw2dSolver(nodes=nodes, g=G, device=0, flags=sw2d.REORDER if args.reorder else 0)
     h, hu, hv = initial_state(ctx.x, ctx.y)
     solver.setState(h, hu, hv)
     dt, _ = solver.computeDt(CFL)
@@ -135,26 +135,29 @@ def run_single(args):
     achieved = bytes_elem * K / (ms_per_launch * 1e-3) / 1e9
     traffic, traffic_src = committed_traffic()
     line = {
-        "metric": "element-DOF updates/sec (sw2d RHS + LSERK4 stage, N=4, 1M tris)",
+        "metric": f"element-DOF updates/sec (sw2d RHS + LSERK4 stage, N={ORDER}, {K / 1e6:g}M tris)",
         "value": Np * K * args.steps / wall,
         "unit": "element-DOF updates/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "sw2d RHS + fused LSERK4 stage, synthetic box 1000x500 cells = 1e6 triangles, "
-                               "N=4 (Np=15), natural element order, walls on all sides",
+        "config": {"workload": f"sw2d RHS + fused LSERK4 stage, synthetic box {NX}x{NY} cells = {K} triangles, "
+                               f"N={ORDER} (Np={Np}), " + (f"element order shuffled (seed {args.shuffle_seed})"
+                               
+                               if args.shuffle_seed else "natural element order") + ", walls on all sides",
                    "order": ORDER, "elements": K, "fields": 3, "step": "one fused RHS+LSERK4 stage launch",
                    "geometry": "affine (one metric set per element, one normal/scale per face)"
                                if solver.usesAffineGeometry else "nodal",
                    "actual_hbm_bytes_per_element": actual_bytes_per_element(ORDER, solver.usesAffineGeometry),
+                   "renumbered_internally": solver.isRenumbered,
                    "dt": dt, "eta_max_after": eta_max, "setup_seconds": round(t_setup, 2),
                    "device_bytes": solver.deviceBytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_elem * K, "kernel_ms": ms_per_launch,
                      "measured_stream_triad_GBps": triad, "same_access_pattern_no_compute_ms": probe_ms,
-                     "kernel": "sw2d_stage_affine_kernel<4, MODE_LSERK>" if solver.usesAffineGeometry else "sw2d_stage_kernel<4, MODE_LSERK, false>"},
+                     "kernel": ("sw2d_stage_affine_fieldsplit_kernel" if ORDER > 6 else "sw2d_stage_affine_kernel") + f"<{ORDER}, MODE_LSERK>" if solver.usesAffineGeometry else f"sw2d_stage_kernel<{ORDER}, MODE_LSERK, false>"},
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(ORDER)
@@ -257,12 +260,19 @@ def run_distributed(args):
 
 
 def main():
+    global ORDER, NX, NY
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--order", type=int, default=ORDER, help="polynomial order (default: the BASELINE metric's N=4)")
+    ap.add_argument("--cells", default=f"{NX}x{NY}", help="box cells NXxNY, 2 triangles each (default 1000x500)")
+    ap.add_argument("--shuffle-seed", type=int, default=0, help="Fisher-Yates element shuffle (adversarial ordering)")
+    ap.add_argument("--reorder", action="store_true", help="let the solver renumber elements internally (BFS)")
     args = ap.parse_args()
+    ORDER = args.order
+    NX, NY = (int(v) for v in args.cells.lower().split("x"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("BDG_BENCH_FORCE_DISTRIBUTED") == "1":
         run_distributed(args)

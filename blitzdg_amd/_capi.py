@@ -17,6 +17,7 @@ BDG_OK, BDG_ERR_ARGUMENT, BDG_ERR_RUNTIME, BDG_ERR_HIP, BDG_ERR_UNSTABLE = 0, 1,
 BDG_F64, BDG_I32 = 0, 1
 BDG_SW2D_REORDER = 1
 BDG_SW2D_NODAL_GEOMETRY = 2
+BDG_SW2D_KEEP_ORDER = 4
 
 # enum values, in header order
 (MESH_VERTICES, MESH_ELEMENTS, MESH_ETOE, MESH_ETOF, MESH_BCTYPE, MESH_EPART, MESH_NPART) = range(7)
@@ -128,6 +129,7 @@ _SIGNATURES = {
     "bdg_probe_stream_triad": (c_int, [c_int, c_size_t, c_int, POINTER(c_double)]),
     "bdg_sw2d_probe_stage_traffic": (c_int, [_P, c_int, POINTER(c_float)]),
     "bdg_sw2d_uses_affine_geometry": (c_int, [_P]),
+    "bdg_sw2d_is_renumbered": (c_int, [_P]),
     "bdg_sw2d_device_bytes": (c_size_t, [_P]),
     "bdg_sw2d_stream": (c_void_p, [_P]),
 }

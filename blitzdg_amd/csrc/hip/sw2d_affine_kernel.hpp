@@ -473,20 +473,34 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_stage_affine_stream_kernel(co
 namespace bdg_dev {
 
 // ---------------------------------------------------------------------------------------------
-// Field-split variant for high order (N >= 7, where 3*Np accumulators no longer fit the 256
-// architectural VGPRs a vector FMA can address): a workgroup is three wavefronts over the SAME
-// 64 elements, wave c accumulating only field c (Np accumulators). The pointwise physics (fluxes,
-// wave speeds, Lax-Friedrichs jump) is evaluated by all three waves -- it is O(Np) against the
-// O(Np^2) contractions -- and their redundant loads of the element's state hit L1/L2.
-template <int N, int MODE>
-__global__ __launch_bounds__(192) void sw2d_stage_affine_fieldsplit_kernel(const StageParams p) {
+// Rolled variant for higher orders. The fully unrolled kernels above put the whole operator
+// (2*Np^2 + 3*Nfp*Np scalar operands) into one basic block; beyond N=5 the compiler then spills
+// thousands of SGPRs/VGPRs. Here the loops over the INPUT node (volume) and over the face nodes
+// (surface) are real loops whose body is one operator row applied to the accumulators, so code
+// size and register use grow with Np, not Np^2, and 2+ waves share a SIMD.
+//   FIELDS = 3: one wavefront lane updates all three fields of its element (3*Np accumulators);
+//   FIELDS = 1: a workgroup is three wavefronts over the SAME 64 elements, wave c accumulating
+//               field c only (Np accumulators) -- needed from N=7 on, where 3*Np doubles no longer
+//               fit the 256 architectural VGPRs a vector FMA can address. The pointwise physics is
+//               evaluated by all three waves (O(Np) against the O(Np^2) contractions) and their
+//               redundant loads of the element state hit L1/L2.
+template <int N>
+__device__ __forceinline__ int fmask_rt(int f, int n) {
+    const int rs = n * (N + 1) - (n * (n - 1)) / 2;
+    return f == 0 ? n : (f == 1 ? rs + (N - n) : rs);
+}
+
+template <int N, int MODE, int FIELDS>
+__global__ __launch_bounds__(FIELDS == 3 ? 256 : 192, 2) void sw2d_stage_affine_rolled_kernel(const StageParams p) {
     using E = Elem<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp;
+    static_assert(FIELDS == 1 || FIELDS == 3, "FIELDS is 1 or 3");
 
     const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
     const unsigned tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
-    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // field of this wave (uniform)
-    const unsigned k = static_cast<unsigned>(p.kbegin) + tile * 64u + (threadIdx.x & 63u);
+    const int c = FIELDS == 3 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // field of this wave
+    const unsigned k = static_cast<unsigned>(p.kbegin) +
+                       (FIELDS == 3 ? tile * 256u + threadIdx.x : tile * 64u + (threadIdx.x & 63u));
     if (k >= static_cast<unsigned>(p.kend)) return;
     const unsigned k8 = k * 8u, k4 = k * 4u;
 
@@ -496,149 +510,143 @@ __global__ __launch_bounds__(192) void sw2d_stage_affine_fieldsplit_kernel(const
     const double* __restrict__ ag = p.ageo;
     const double g = p.g, halfg = 0.5 * p.g;
 
-    double R[Np];
+    double R[FIELDS][Np];
 #pragma unroll
-    for (int i = 0; i < Np; ++i) R[i] = 0.0;
+    for (int q = 0; q < FIELDS; ++q)
+#pragma unroll
+        for (int i = 0; i < Np; ++i) R[q][i] = 0.0;
 
-    // ---- volume term
+    // ---- volume term: one input node per iteration, next node's state in flight
     {
         const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
                      sy = ld_row(ag + 3 * ld, k8);
-        constexpr int VCH = 5, NCH = (Np + VCH - 1) / VCH;
-        double hc[2][VCH], huc[2][VCH], hvc[2][VCH];
+        double h = ld_row(qin, k8), hu = ld_row(qin + plane, k8), hv = ld_row(qin + 2 * plane, k8);
+#pragma unroll 1
+        for (int m = 0; m < Np; ++m) {
+            const int mn = m + 1 < Np ? m + 1 : m;
+            const double hn = ld_row(qin + mn * ld, k8), hun = ld_row(qin + plane + mn * ld, k8),
+                         hvn = ld_row(qin + 2 * plane + mn * ld, k8);
+            const double r = fast_rcp(h);
+            const double u = hu * r, v = hv * r;
+            const double pr = halfg * h * h;
+            const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
+            const double* __restrict__ row = ops + AffineOps<N>::OFF_D + 2 * m * Np;
+            if constexpr (FIELDS == 3) {
+                const double a1 = -(rx * hu + ry * hv), b1 = -(sx * hu + sy * hv);
+                const double a2 = -(rx * F2 + ry * G2), b2 = -(sx * F2 + sy * G2);
+                const double a3 = -(rx * G2 + ry * G3), b3 = -(sx * G2 + sy * G3);
 #pragma unroll
-        for (int t = 0; t < VCH; ++t)
-            if (t < Np) {
-                hc[0][t] = ld_row(qin + t * ld, k8);
-                huc[0][t] = ld_row(qin + plane + t * ld, k8);
-                hvc[0][t] = ld_row(qin + 2 * plane + t * ld, k8);
-            }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int cur = ch & 1, nxt = cur ^ 1;
-#pragma unroll
-            for (int t = 0; t < VCH; ++t) {
-                const int m = (ch + 1) * VCH + t;
-                if (m < Np) {
-                    hc[nxt][t] = ld_row(qin + m * ld, k8);
-                    huc[nxt][t] = ld_row(qin + plane + m * ld, k8);
-                    hvc[nxt][t] = ld_row(qin + 2 * plane + m * ld, k8);
+                for (int i = 0; i < Np; ++i) {
+                    const double dr = row[2 * i], ds = row[2 * i + 1];
+                    R[0][i] = fma(ds, b1, fma(dr, a1, R[0][i]));
+                    R[FIELDS - 2][i] = fma(ds, b2, fma(dr, a2, R[FIELDS - 2][i]));
+                    R[FIELDS - 1][i] = fma(ds, b3, fma(dr, a3, R[FIELDS - 1][i]));
                 }
+            } else {
+                const double F = c == 0 ? hu : (c == 1 ? F2 : G2);
+                const double G = c == 0 ? hv : (c == 1 ? G2 : G3);
+                const double a = -(rx * F + ry * G), b = -(sx * F + sy * G);
+#pragma unroll
+                for (int i = 0; i < Np; ++i) R[0][i] = fma(row[2 * i + 1], b, fma(row[2 * i], a, R[0][i]));
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < VCH; ++t) {
-                const int m = ch * VCH + t;
-                if (m < Np) {
-                    const double h = hc[cur][t], hu = huc[cur][t], hv = hvc[cur][t];
-                    const double r = fast_rcp(h);
-                    const double u = hu * r, v = hv * r;
-                    const double pr = halfg * h * h;
-                    const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
-                    const double F = c == 0 ? hu : (c == 1 ? F2 : G2);
-                    const double G = c == 0 ? hv : (c == 1 ? G2 : G3);
-                    const double a = -(rx * F + ry * G), b = -(sx * F + sy * G);
-#pragma unroll
-                    for (int i = 0; i < Np; ++i) R[i] = fma(ops[AffineOps<N>::OFF_D + 2 * (m * Np + i)], a, R[i]);
-#pragma unroll
-                    for (int i = 0; i < Np; ++i) R[i] = fma(ops[AffineOps<N>::OFF_D + 2 * (m * Np + i) + 1], b, R[i]);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
+            h = hn; hu = hun; hv = hvn;
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- surface term
-#pragma unroll
+    // ---- surface term: per face, pass 1 finds the Lax-Friedrichs speed, pass 2 lifts the jumps
+#pragma unroll 1
     for (int f = 0; f < 3; ++f) {
         const double nxf = ld_row(ag + (4 + f) * ld, k8), nyf = ld_row(ag + (7 + f) * ld, k8);
         const double half_fs = 0.5 * ld_row(ag + (10 + f) * ld, k8);
-        int idx[Nfp];
-        double hM[Nfp], huM[Nfp], hvM[Nfp], hq[Nfp], huq[Nfp], hvq[Nfp];
-#pragma unroll
-        for (int n = 0; n < Nfp; ++n) idx[n] = ld_row(p.vmapP + (f * Nfp + n) * ld, k4);
-#pragma unroll
-        for (int n = 0; n < Nfp; ++n) {
-            const int m = E::fmask(f, n);
-            hM[n] = ld_row(qin + m * ld, k8);
-            huM[n] = ld_row(qin + plane + m * ld, k8);
-            hvM[n] = ld_row(qin + 2 * plane + m * ld, k8);
-        }
-#pragma unroll
-        for (int n = 0; n < Nfp; ++n) {
-            const unsigned o8 = static_cast<unsigned>(idx[n] < 0 ? -(idx[n] + 1) : idx[n]) * 8u;
-            hq[n] = ld_row(qin, o8);
-            huq[n] = ld_row(qin + plane, o8);
-            hvq[n] = ld_row(qin + 2 * plane, o8);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         double lam = 0.0;
-#pragma unroll
-        for (int n = 0; n < Nfp; ++n) {
-            if (idx[n] < 0) { // reflective wall
-                const double un = huM[n] * nxf + hvM[n] * nyf;
-                huq[n] = huM[n] - 2 * nxf * un;
-                hvq[n] = hvM[n] - 2 * nyf * un;
-            }
-            const double rM = fast_rcp(hM[n]), rP = fast_rcp(hq[n]);
-            const double uM = huM[n] * rM, vM = hvM[n] * rM, uP = huq[n] * rP, vP = hvq[n] * rP;
-            const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM[n]);
-            const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq[n]);
-            lam = fmax(lam, fmax(spdM, spdP));
-        }
-#pragma unroll
-        for (int n = 0; n < Nfp; ++n) {
-            const int j = f * Nfp + n;
-            const double rM = fast_rcp(hM[n] * p.one), rP = fast_rcp(hq[n] * p.one);
-            const double uM = huM[n] * rM, vM = hvM[n] * rM, uP = huq[n] * rP, vP = hvq[n] * rP;
-            const double prM = halfg * hM[n] * hM[n], prP = halfg * hq[n] * hq[n];
-            const double F2M = huM[n] * uM + prM, G2M = huM[n] * vM, G3M = hvM[n] * vM + prM;
-            const double F2P = huq[n] * uP + prP, G2P = huq[n] * vP, G3P = hvq[n] * vP + prP;
-            const double dh = hM[n] - hq[n], dhu = huM[n] - huq[n], dhv = hvM[n] - hvq[n];
-            const double dF = c == 0 ? dhu : (c == 1 ? F2M - F2P : G2M - G2P);
-            const double dG = c == 0 ? dhv : (c == 1 ? G2M - G2P : G3M - G3P);
-            const double dq = c == 0 ? dh : (c == 1 ? dhu : dhv);
-            const double s = half_fs * (dF * nxf + dG * nyf - lam * dq);
-#pragma unroll
-            for (int i = 0; i < Np; ++i) R[i] = fma(ops[AffineOps<N>::OFF_LIFT + j * Np + i], s, R[i]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // ---- stage update / output of this wave's field
-    const long long fo = static_cast<long long>(c) * plane;
-    if constexpr (MODE == MODE_RHS) {
-#pragma unroll
-        for (int i = 0; i < Np; ++i) st_row(p.rhs + fo + i * ld, k8, R[i]);
-    } else {
-        constexpr int CH = 9;
-        const double* __restrict__ base2 = ((MODE == MODE_LSERK) ? p.res : p.qbase) + fo;
-        const double a = p.ca, b = p.cb, cc = p.cc;
-#pragma unroll
-        for (int i0 = 0; i0 < Np; i0 += CH) {
-            double q1[CH], o1[CH];
-#pragma unroll
-            for (int t = 0; t < CH; ++t)
-                if (i0 + t < Np) {
-                    q1[t] = ld_row(qin + fo + (i0 + t) * ld, k8);
-                    o1[t] = ld_row(base2 + (i0 + t) * ld, k8);
+#pragma unroll 1
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll 1
+            for (int n = 0; n < Nfp; ++n) {
+                const int j = f * Nfp + n, m = fmask_rt<N>(f, n);
+                const int id = ld_row(p.vmapP + j * ld, k4);
+                const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
+                             hvM = ld_row(qin + 2 * plane + m * ld, k8);
+                const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
+                const double hq = ld_row(qin, o8);
+                double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
+                if (id < 0) { // reflective wall: no normal flow
+                    const double un = huM * nxf + hvM * nyf;
+                    huq = huM - 2 * nxf * un;
+                    hvq = hvM - 2 * nyf * un;
                 }
-            __builtin_amdgcn_sched_barrier(0);
+                const double rM = fast_rcp(hM), rP = fast_rcp(hq);
+                const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
+                if (pass == 0) {
+                    const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                    const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                    lam = fmax(lam, fmax(spdM, spdP));
+                } else {
+                    const double prM = halfg * hM * hM, prP = halfg * hq * hq;
+                    const double F2M = huM * uM + prM, G2M = huM * vM, G3M = hvM * vM + prM;
+                    const double F2P = huq * uP + prP, G2P = huq * vP, G3P = hvq * vP + prP;
+                    const double dh = hM - hq, dhu = huM - huq, dhv = hvM - hvq;
+                    const double* __restrict__ row = ops + AffineOps<N>::OFF_LIFT + j * Np;
+                    if constexpr (FIELDS == 3) {
+                        const double s1 = half_fs * (dhu * nxf + dhv * nyf - lam * dh);
+                        const double s2 = half_fs * ((F2M - F2P) * nxf + (G2M - G2P) * nyf - lam * dhu);
+                        const double s3 = half_fs * ((G2M - G2P) * nxf + (G3M - G3P) * nyf - lam * dhv);
 #pragma unroll
-            for (int t = 0; t < CH; ++t) {
-                const int i = i0 + t;
-                if (i < Np) {
-                    if constexpr (MODE == MODE_LSERK) {
-                        const double n1 = a * o1[t] + cc * R[i];
-                        st_row(p.res + fo + i * ld, k8, n1);
-                        st_row(p.qout + fo + i * ld, k8, q1[t] + b * n1);
+                        for (int i = 0; i < Np; ++i) {
+                            const double lj = row[i];
+                            R[0][i] = fma(lj, s1, R[0][i]);
+                            R[FIELDS - 2][i] = fma(lj, s2, R[FIELDS - 2][i]);
+                            R[FIELDS - 1][i] = fma(lj, s3, R[FIELDS - 1][i]);
+                        }
                     } else {
-                        st_row(p.qout + fo + i * ld, k8, a * o1[t] + b * q1[t] + cc * R[i]);
+                        const double dF = c == 0 ? dhu : (c == 1 ? F2M - F2P : G2M - G2P);
+                        const double dG = c == 0 ? dhv : (c == 1 ? G2M - G2P : G3M - G3P);
+                        const double dq = c == 0 ? dh : (c == 1 ? dhu : dhv);
+                        const double s = half_fs * (dF * nxf + dG * nyf - lam * dq);
+#pragma unroll
+                        for (int i = 0; i < Np; ++i) R[0][i] = fma(row[i], s, R[0][i]);
                     }
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- stage update / output (register indices must be static: unrolled, loads in batches)
+#pragma unroll
+    for (int q = 0; q < FIELDS; ++q) {
+        const long long fo = static_cast<long long>(FIELDS == 3 ? q : c) * plane;
+        if constexpr (MODE == MODE_RHS) {
+#pragma unroll
+            for (int i = 0; i < Np; ++i) st_row(p.rhs + fo + i * ld, k8, R[q][i]);
+        } else {
+            constexpr int CH = 7;
+            const double* __restrict__ base2 = ((MODE == MODE_LSERK) ? p.res : p.qbase) + fo;
+            const double a = p.ca, b = p.cb, cc = p.cc;
+#pragma unroll
+            for (int i0 = 0; i0 < Np; i0 += CH) {
+                double q1[CH], o1[CH];
+#pragma unroll
+                for (int t = 0; t < CH; ++t)
+                    if (i0 + t < Np) {
+                        q1[t] = ld_row(qin + fo + (i0 + t) * ld, k8);
+                        o1[t] = ld_row(base2 + (i0 + t) * ld, k8);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < CH; ++t) {
+                    const int i = i0 + t;
+                    if (i < Np) {
+                        if constexpr (MODE == MODE_LSERK) {
+                            const double n1 = a * o1[t] + cc * R[q][i];
+                            st_row(p.res + fo + i * ld, k8, n1);
+                            st_row(p.qout + fo + i * ld, k8, q1[t] + b * n1);
+                        } else {
+                            st_row(p.qout + fo + i * ld, k8, a * o1[t] + b * q1[t] + cc * R[q][i]);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }

@@ -244,7 +244,8 @@ struct bdg_sw2d {
     DevBuf<double> qA, qB, res, aux, geo, fgeo, ops, Hbuf, stage, partials, red2;
     DevBuf<double> ageo, opsAffine, opsAffineFiltered; // affine-geometry fast path
     bool affine = false;
-    int affineVariant = 0; // 0: register-resident state; 2/3: streamed state at 2/3 waves per SIMD
+    int affineVariant = 0; // 0: unrolled, register-resident state; 2/3: unrolled, streamed state at 2/3 waves
+                           // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane
     DevBuf<int> vmapP, perm, istage, sendSlots;
     int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
     // native halo exchange (RCCL over xGMI): one send and one receive range per neighbour rank
@@ -469,8 +470,11 @@ std::vector<int> bfsOrder(const int* vmapP, int K, int Np, int Nfp) {
 
 // True when the metric terms are constant per element and the face terms constant per
 // face (straight-sided elements), to round-off: then one value per element/face suffices.
+// The tables themselves carry round-off from Dr*x on small elements (relative ~1e-16 * |Dr| / h:
+// 5e-11 at N=8 on a 500x250-cell box), so the test is 1e-8: far above that noise, far below any
+// real curvature.
 bool geometryIsAffine(const bdg_sw2d_desc& d, int Np, int Nfp, int K) {
-    const double tol = 1e-11;
+    const double tol = 1e-8;
     bool ok = true;
 #pragma omp parallel for schedule(static) reduction(&& : ok)
     for (int k = 0; k < K; ++k) {
@@ -564,7 +568,20 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
         if (d.mapW[i] < 0 || static_cast<size_t>(d.mapW[i]) >= nFaceNodes)
             throw arg_error("bdg_sw2d_create: wall-node index out of range");
 
-    if (d.flags & BDG_SW2D_REORDER) s->permHost = bfsOrder(d.vmapP, K, Np, Nfp);
+    // Element numbering: the trace gather is cheap only when face neighbours sit within an L2-sized
+    // window of slots. Forced by BDG_SW2D_REORDER, suppressed by BDG_SW2D_KEEP_ORDER, otherwise
+    // decided from the mean neighbour distance (shuffled 10^6-triangle box: 1.11 ms as given,
+    // 0.37 ms renumbered; natural order: 0.38 ms either way).
+    bool reorder = (d.flags & BDG_SW2D_REORDER) != 0;
+    if (!reorder && !(d.flags & BDG_SW2D_KEEP_ORDER)) {
+        double sum = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : sum)
+        for (int k = 0; k < K; ++k)
+            for (int f = 0; f < 3; ++f)
+                sum += std::fabs(static_cast<double>(d.vmapP[(static_cast<size_t>(k) * 3 + f) * Nfp] / Np - k));
+        reorder = sum / (3.0 * K) > 4.0 * std::sqrt(static_cast<double>(K));
+    }
+    if (reorder) s->permHost = bfsOrder(d.vmapP, K, Np, Nfp);
     s->affine = !(d.flags & BDG_SW2D_NODAL_GEOMETRY) && geometryIsAffine(d, Np, Nfp, K);
     if (!s->affine && kt->ldsDoubles == 0)
         throw arg_error("bdg_sw2d_create: orders above 6 are implemented for straight-sided (affine) geometry only");
@@ -634,9 +651,12 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->uploadRows(d.Fscale, s->fscaleNodal, NFN);
 
     // ---- affine fast path: one metric value per element, one normal/scale per face
+    // Measured on MI355X: the fully unrolled kernel wins up to N=5; from N=6 on its
+    // basic block outgrows the register files and the rolled one-field-per-wave kernel is faster.
+    s->affineVariant = s->N <= 5 ? 0 : 1;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 3) s->affineVariant = v;
+        if (v >= 0 && v <= 4) s->affineVariant = v;
     }
     if (s->affine) {
         s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);
@@ -889,7 +909,8 @@ int bdg_sw2d_time_lserk4_stages(bdg_sw2d* s, double dt, int num_stages, float* m
 int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const int* send_elements, int num_send) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_set_partition");
-        if (!s->permHost.empty()) throw arg_error("bdg_sw2d_set_partition: not available together with BDG_SW2D_REORDER");
+        if (!s->permHost.empty())
+            throw arg_error("bdg_sw2d_set_partition: the solver renumbered its elements; create it with BDG_SW2D_KEEP_ORDER");
         if (num_interior < 0 || num_interior > num_owned || num_owned > s->K || num_send < 0 ||
             (num_send > 0 && !send_elements))
             throw arg_error("bdg_sw2d_set_partition: need 0 <= num_interior <= num_owned <= K");
@@ -1113,6 +1134,7 @@ int bdg_sw2d_probe_stage_traffic(bdg_sw2d* s, int repeats, float* ms_per_launch)
 }
 
 int bdg_sw2d_uses_affine_geometry(const bdg_sw2d* s) { return s ? (s->affine ? 1 : 0) : -1; }
+int bdg_sw2d_is_renumbered(const bdg_sw2d* s) { return s ? (s->permHost.empty() ? 0 : 1) : -1; }
 
 size_t bdg_sw2d_device_bytes(const bdg_sw2d* s) { return s ? s->bytes : 0; }
 void* bdg_sw2d_stream(bdg_sw2d* s) { return s ? static_cast<void*>(s->stream) : nullptr; }

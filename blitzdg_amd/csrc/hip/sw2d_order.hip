@@ -13,22 +13,29 @@ constexpr int kBlock = 256;
 // Orders above this use the field-split kernels only (3*Np accumulators exceed the VGPR file).
 constexpr bool kHighOrder = BDG_ORDER > 6;
 
-template <int MODE>
-hipError_t launchFieldSplit(const StageParams& p, hipStream_t stream) {
+// Rolled kernels. FIELDS = 1 (three waves per 64 elements, one field each) exists for every
+// order; FIELDS = 3 (all fields per lane) only where 3*Np accumulators fit (N <= 6).
+template <int MODE, int FIELDS>
+hipError_t launchRolled(const StageParams& p, hipStream_t stream) {
     if (p.kend <= p.kbegin) return hipSuccess;
-    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
-    hipLaunchKernelGGL((sw2d_stage_affine_fieldsplit_kernel<kN, MODE>), dim3(grid), dim3(192), 0, stream, p);
+    const int per = FIELDS == 3 ? 256 : 64;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + per - 1) / per);
+    hipLaunchKernelGGL((sw2d_stage_affine_rolled_kernel<kN, MODE, FIELDS>), dim3(grid), dim3(FIELDS == 3 ? 256 : 192), 0,
+                       stream, p);
     return hipGetLastError();
 }
 
-hipError_t stageFieldSplit(int mode, const StageParams& p, hipStream_t stream) {
+template <int FIELDS>
+hipError_t stageRolled(int mode, const StageParams& p, hipStream_t stream) {
     switch (mode) {
-    case MODE_RHS: return launchFieldSplit<MODE_RHS>(p, stream);
-    case MODE_LSERK: return launchFieldSplit<MODE_LSERK>(p, stream);
-    case MODE_COMBINE: return launchFieldSplit<MODE_COMBINE>(p, stream);
+    case MODE_RHS: return launchRolled<MODE_RHS, FIELDS>(p, stream);
+    case MODE_LSERK: return launchRolled<MODE_LSERK, FIELDS>(p, stream);
+    case MODE_COMBINE: return launchRolled<MODE_COMBINE, FIELDS>(p, stream);
     default: return hipErrorInvalidValue;
     }
 }
+
+hipError_t stageFieldSplit(int mode, const StageParams& p, hipStream_t stream) { return stageRolled<1>(mode, p, stream); }
 
 template <int MODE, bool FILTER>
 hipError_t launchStage(const StageParams& p, hipStream_t stream) {
@@ -76,6 +83,10 @@ hipError_t launchStream(const StageParams& p, hipStream_t stream) {
 // variant: 0 = register-resident state (1 wave/SIMD), 2 / 3 = streamed state at 2 / 3 waves per SIMD
 hipError_t stageAffine(int mode, int variant, const StageParams& p, hipStream_t stream) {
     if (variant == 1) return stageFieldSplit(mode, p, stream);
+    if (variant == 4) {
+        if constexpr (kHighOrder) return stageFieldSplit(mode, p, stream);
+        else return stageRolled<3>(mode, p, stream);
+    }
     if (variant == 2) {
         switch (mode) {
         case MODE_RHS: return launchStream<MODE_RHS, 2>(p, stream);

@@ -170,7 +170,7 @@ class NativeDistributedSw2d:
         self.plan, self.order = plan, order
         self.mesh = build_local_mesh(plan)
         self.nodes = dg.TriangleNodesProvisioner(order, self.mesh)
-        self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device)
+        self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device, flags=sw2d.KEEP_ORDER)
         self.Np = self.solver.Np
         send = np.ascontiguousarray(plan.send_local, dtype=np.int32)
         check(lib.bdg_sw2d_set_partition(self.solver._h, plan.num_interior, plan.num_owned, ptr(send), send.size))
@@ -270,7 +270,7 @@ class DistributedSw2d:
         self.nodes = dg.TriangleNodesProvisioner(order, self.mesh)
         if filter_args is not None:
             self.nodes.buildFilter(*filter_args)
-        self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device)
+        self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device, flags=sw2d.KEEP_ORDER)
         self.Np, self.K_loc = self.solver.Np, self.solver.K
         send = np.ascontiguousarray(plan.send_local, dtype=np.int32)
         check(lib.bdg_sw2d_set_partition(self.solver._h, plan.num_interior, plan.num_owned, ptr(send), send.size))

@@ -18,6 +18,7 @@ from ._capi import byref, c_double, c_float, c_int, c_void_p, check, lib
 
 REORDER = C.BDG_SW2D_REORDER
 NODAL_GEOMETRY = C.BDG_SW2D_NODAL_GEOMETRY
+KEEP_ORDER = C.BDG_SW2D_KEEP_ORDER
 
 
 class Sw2dSolver:
@@ -130,6 +131,10 @@ class Sw2dSolver:
         ms = c_float()
         check(lib.bdg_sw2d_probe_stage_traffic(self._h, int(repeats), byref(ms)))
         return ms.value
+
+    @property
+    def isRenumbered(self):
+        return bool(lib.bdg_sw2d_is_renumbered(self._h))
 
     @property
     def usesAffineGeometry(self):

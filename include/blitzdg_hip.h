@@ -157,6 +157,9 @@ typedef struct bdg_sw2d_desc {
 #define BDG_SW2D_MAX_ORDER 8 /* 7 and 8: straight-sided (affine) geometry only */
 #define BDG_SW2D_REORDER 1u /* renumber elements internally for gather locality (results are
                                returned in the caller's numbering either way)         */
+#define BDG_SW2D_KEEP_ORDER 4u /* never renumber (default: renumber when the mean face-neighbour
+                               distance exceeds 4*sqrt(K) slots, e.g. a shuffled mesh). Required
+                               for bdg_sw2d_set_partition, whose element ranges are in caller order */
 #define BDG_SW2D_NODAL_GEOMETRY 2u /* always read rx..sy, nx, ny, Fscale per node (general path).
                                Default: if they are constant per element / per face to round-off
                                (straight-sided elements: everything the reference's provisioner
@@ -238,6 +241,8 @@ int bdg_probe_stream_triad(int device, size_t bytes_per_array, int repeats, doub
 int bdg_sw2d_probe_stage_traffic(bdg_sw2d* s, int repeats, float* ms_per_launch);
 /* 1 if the solver runs the affine-geometry kernels, 0 for the per-node-geometry kernels. */
 int bdg_sw2d_uses_affine_geometry(const bdg_sw2d* s);
+/* 1 if the solver renumbered the elements internally (I/O stays in the caller's numbering). */
+int bdg_sw2d_is_renumbered(const bdg_sw2d* s);
 size_t bdg_sw2d_device_bytes(const bdg_sw2d* s);
 /* The raw stream (hipStream_t) launches are issued on, for callers that interleave their own work. */
 void* bdg_sw2d_stream(bdg_sw2d* s);

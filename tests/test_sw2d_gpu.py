@@ -68,6 +68,16 @@ def test_drop_in_compute_rhs_signature(coarse_mesh):
     assert max(np.abs(a - b).max() for a, b in zip(r, ref)) / scale < RHS_TOL
 
 
+def test_automatic_renumbering_decision():
+    nat, shuf = dg.MeshManager(), dg.MeshManager()
+    nat.buildBoxMesh(60, 40)
+    shuf.buildBoxMesh(60, 40, shuffleSeed=9)
+    assert not sw2d.Sw2dSolver(nodes=dg.TriangleNodesProvisioner(2, nat)).isRenumbered
+    assert sw2d.Sw2dSolver(nodes=dg.TriangleNodesProvisioner(2, shuf)).isRenumbered
+    assert not sw2d.Sw2dSolver(nodes=dg.TriangleNodesProvisioner(2, shuf), flags=sw2d.KEEP_ORDER).isRenumbered
+    assert sw2d.Sw2dSolver(nodes=dg.TriangleNodesProvisioner(2, nat), flags=sw2d.REORDER).isRenumbered
+
+
 def test_state_roundtrip_and_padding(coarse_mesh):
     nodes = dg.TriangleNodesProvisioner(2, coarse_mesh)  # K = 40 is not a multiple of 64
     for flags in (0, sw2d.REORDER):
@@ -229,7 +239,7 @@ def test_medium_box_meshes_vs_oracle(order, nx, ny, seed):
     scale = max(np.abs(x).max() for x in ref)
     dt = 0.5 * o.dt(h, hu, hv, 0.65, order)
     ref_state = o.step_lserk4(h, hu, hv, dt, 2)
-    for flags in (0, sw2d.REORDER, sw2d.NODAL_GEOMETRY):
+    for flags in (0, sw2d.REORDER, sw2d.KEEP_ORDER, sw2d.NODAL_GEOMETRY):
         if order > 6 and flags & sw2d.NODAL_GEOMETRY:
             continue
         s = sw2d.Sw2dSolver(nodes=nodes, flags=flags)
