@@ -50,7 +50,9 @@ class Sw2dDesc(Structure):
                 ("rx", c_void_p), ("sx", c_void_p), ("ry", c_void_p), ("sy", c_void_p),
                 ("nx", c_void_p), ("ny", c_void_p), ("Fscale", c_void_p),
                 ("vmapM", c_void_p), ("vmapP", c_void_p), ("mapW", c_void_p), ("num_wall", c_int),
-                ("g", c_double), ("device", c_int), ("flags", c_int)]
+                ("g", c_double), ("device", c_int), ("flags", c_int),
+                ("num_fields", c_int), ("sources", c_int), ("zx", c_void_p), ("zy", c_void_p),
+                ("coriolis", c_void_p), ("coriolis_const", c_double), ("drag", c_double)]
 
 
 def _load():
@@ -106,6 +108,10 @@ _SIGNATURES = {
     "bdg_sw2d_get_state": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_set_bathymetry": (c_int, [_P, _P]),
     "bdg_sw2d_rhs": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int]),
+    "bdg_sw2d_set_state4": (c_int, [_P, _P, _P, _P, _P]),
+    "bdg_sw2d_get_state4": (c_int, [_P, _P, _P, _P, _P]),
+    "bdg_sw2d_rhs4": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
+    "bdg_sw2d_num_fields": (c_int, [_P]),
     "bdg_sw2d_step_lserk4": (c_int, [_P, c_double, c_int]),
     "bdg_sw2d_lserk4_stages": (c_int, [_P, c_double, c_int]),
     "bdg_sw2d_step_rk2": (c_int, [_P, c_double, c_int, c_int]),

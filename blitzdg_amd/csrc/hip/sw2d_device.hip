@@ -244,6 +244,11 @@ struct bdg_sw2d {
     DevBuf<double> qA, qB, res, aux, geo, fgeo, ops, Hbuf, stage, partials, red2;
     DevBuf<double> ageo, opsAffine, opsAffineFiltered; // affine-geometry fast path
     bool affine = false;
+    // variant D (reference swhelpers/rhs.py:178-311): optional tracer field and source terms
+    int nf = 3;
+    bool variantD = false;
+    bdg_dev::VdParams vd{};
+    DevBuf<double> zxBuf, zyBuf, fcorBuf, opsVd, opsVdFiltered;
     int affineVariant = 0; // 0: unrolled, register-resident state; 2/3: unrolled, streamed state at 2/3 waves
                            // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane
     DevBuf<int> vmapP, perm, istage, sendSlots;
@@ -315,7 +320,10 @@ struct bdg_sw2d {
     // One fused pass. The affine path takes the filter through pre-multiplied operators.
     void launchStage(int mode, bool filter, bdg_dev::StageParams& p, const char* what) {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
-        if (affine) {
+        if (variantD) {
+            p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
+            hipCheck(kt->stageVd(mode, p, vd, stream), what);
+        } else if (affine) {
             p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
             hipCheck(kt->stageAffine(mode, affineVariant, p, stream), what);
         } else {
@@ -353,7 +361,7 @@ struct bdg_sw2d {
 
     void launchPack(double* buf) {
         if (numSend == 0) return;
-        const int rows = 3 * Np;
+        const int rows = nf * Np;
         const long long n = static_cast<long long>(numSend) * rows;
         hipLaunchKernelGGL(bdg_dev::halo_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream,
                            qcur, buf, sendSlots.p, numSend, rows, ld);
@@ -362,7 +370,7 @@ struct bdg_sw2d {
     void launchUnpack(const double* buf) {
         const int ghosts = K - numOwned;
         if (ghosts == 0) return;
-        const int rows = 3 * Np;
+        const int rows = nf * Np;
         const long long n = static_cast<long long>(ghosts) * rows;
         hipLaunchKernelGGL(bdg_dev::halo_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
                            stream, qcur, buf, numOwned, ghosts, rows, ld);
@@ -376,7 +384,7 @@ struct bdg_sw2d {
     // pack is ordered after the previous stage's exchange completed on the compute stream.
     void launchLserkStageExchanged() {
         if (!comm) throw arg_error("no communicator: call bdg_sw2d_comm_init first");
-        const int rows = 3 * Np;
+        const int rows = nf * Np;
         launchPack(sendBuf.p);
         hipCheck(hipEventRecord(evPacked, stream), "hipEventRecord");
         hipCheck(hipStreamWaitEvent(commStream, evPacked, 0), "hipStreamWaitEvent");
@@ -545,6 +553,10 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->N = d.order; s->Np = kt->Np; s->Nfp = kt->Nfp; s->NFN = 3 * kt->Nfp; s->K = d.num_elements;
     s->device = d.device;
     s->g = d.g;
+    if (d.num_fields != 0 && d.num_fields != 3 && d.num_fields != 4)
+        throw arg_error("bdg_sw2d_create: num_fields must be 3 or 4");
+    s->nf = d.num_fields == 4 ? 4 : 3;
+    s->variantD = s->nf == 4 || d.sources != 0;
     s->ld = (static_cast<long long>(s->K) + 63) / 64 * 64;
     s->numInterior = s->numOwned = s->K;
     const int Np = s->Np, Nfp = s->Nfp, NFN = s->NFN, K = s->K;
@@ -585,13 +597,15 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->affine = !(d.flags & BDG_SW2D_NODAL_GEOMETRY) && geometryIsAffine(d, Np, Nfp, K);
     if (!s->affine && kt->ldsDoubles == 0)
         throw arg_error("bdg_sw2d_create: orders above 6 are implemented for straight-sided (affine) geometry only");
+    if (!s->affine && s->variantD)
+        throw arg_error("bdg_sw2d_create: tracer / source terms are implemented for straight-sided (affine) geometry only");
 
     s->use();
     hipCheck(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
     hipCheck(hipEventCreate(&s->ev0), "hipEventCreate");
     hipCheck(hipEventCreate(&s->ev1), "hipEventCreate");
 
-    const size_t plane3 = 3 * s->planeSize();
+    const size_t plane3 = static_cast<size_t>(s->nf) * s->planeSize();
     s->qA.alloc(plane3, s->bytes);
     s->qB.alloc(plane3, s->bytes);
     s->res.alloc(plane3, s->bytes);
@@ -686,6 +700,51 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
         }
     }
 
+    // ---- variant D: operator image with a third row per (m, i) (identity or Filter) + source tables
+    if (s->variantD) {
+        auto vdImage = [&](const double* Dr, const double* Ds, const double* F, const double* Lift) {
+            std::vector<double> img(static_cast<size_t>(3) * Np * Np + static_cast<size_t>(NFN) * Np);
+            for (int m = 0; m < Np; ++m)
+                for (int i = 0; i < Np; ++i) {
+                    const size_t o = 3 * (static_cast<size_t>(m) * Np + i);
+                    img[o] = Dr[i * Np + m];
+                    img[o + 1] = Ds[i * Np + m];
+                    img[o + 2] = F ? F[i * Np + m] : (i == m ? 1.0 : 0.0);
+                }
+            for (int j = 0; j < NFN; ++j)
+                for (int i = 0; i < Np; ++i)
+                    img[static_cast<size_t>(3) * Np * Np + static_cast<size_t>(j) * Np + i] = Lift[i * NFN + j];
+            return img;
+        };
+        const std::vector<double> plain = vdImage(d.Dr, d.Ds, nullptr, d.Lift);
+        s->opsVd.alloc(plain.size(), s->bytes);
+        hipCheck(hipMemcpy(s->opsVd.p, plain.data(), plain.size() * sizeof(double), hipMemcpyHostToDevice), "vd ops upload");
+        if (d.Filter) {
+            const std::vector<double> FDr = matmulHost(d.Filter, d.Dr, Np, Np), FDs = matmulHost(d.Filter, d.Ds, Np, Np),
+                                      FL = matmulHost(d.Filter, d.Lift, Np, NFN);
+            const std::vector<double> filt = vdImage(FDr.data(), FDs.data(), d.Filter, FL.data());
+            s->opsVdFiltered.alloc(filt.size(), s->bytes);
+            hipCheck(hipMemcpy(s->opsVdFiltered.p, filt.data(), filt.size() * sizeof(double), hipMemcpyHostToDevice),
+                     "filtered vd ops upload");
+        }
+        s->vd.nf = s->nf;
+        s->vd.sources = d.sources ? 1 : 0;
+        s->vd.fconst = d.coriolis_const;
+        s->vd.cd = d.drag;
+        auto plane = [&](const double* host, DevBuf<double>& buf) -> const double* {
+            if (!host) return nullptr;
+            buf.alloc(s->planeSize(), s->bytes);
+            hipCheck(hipMemsetAsync(buf.p, 0, buf.n * sizeof(double), s->stream), "hipMemset");
+            s->uploadRows(host, buf.p, Np);
+            return buf.p;
+        };
+        if (d.sources) {
+            s->vd.zx = plane(d.zx, s->zxBuf);
+            s->vd.zy = plane(d.zy, s->zyBuf);
+            s->vd.fcor = plane(d.coriolis, s->fcorBuf);
+        }
+    }
+
     // ---- gather offsets: reference numbering (n' + Np*k') -> n'*ld + slot(k'), as (NFN, K) rows;
     //      wall nodes are stored as -(offset+1).
     {
@@ -759,6 +818,7 @@ void bdg_sw2d_destroy(bdg_sw2d* s) {
 int bdg_sw2d_set_state(bdg_sw2d* s, const double* h, const double* hu, const double* hv) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_set_state");
+        if (s->nf != 3) throw arg_error("bdg_sw2d_set_state: this solver has 4 fields, use bdg_sw2d_set_state4");
         if (!h || !hu || !hv) throw arg_error("bdg_sw2d_set_state: NULL field");
         s->use();
         const size_t pl = s->planeSize();
@@ -774,6 +834,7 @@ int bdg_sw2d_set_state(bdg_sw2d* s, const double* h, const double* hu, const dou
 int bdg_sw2d_get_state(bdg_sw2d* s, double* h, double* hu, double* hv) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_get_state");
+        if (s->nf != 3) throw arg_error("bdg_sw2d_get_state: this solver has 4 fields, use bdg_sw2d_get_state4");
         if (!h || !hu || !hv) throw arg_error("bdg_sw2d_get_state: NULL field");
         s->use();
         const size_t pl = s->planeSize();
@@ -799,6 +860,7 @@ int bdg_sw2d_rhs(bdg_sw2d* s, const double* h, const double* hu, const double* h
                  double* r3, int filter) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_rhs");
+        if (s->nf != 3) throw arg_error("bdg_sw2d_rhs: this solver has 4 fields, use bdg_sw2d_rhs4");
         if (!h || !hu || !hv || !r1 || !r2 || !r3) throw arg_error("bdg_sw2d_rhs: NULL field");
         s->use();
         const size_t pl = s->planeSize();
@@ -810,6 +872,54 @@ int bdg_sw2d_rhs(bdg_sw2d* s, const double* h, const double* hu, const double* h
         s->downloadRows(s->aux.p, r1, s->Np);
         s->downloadRows(s->aux.p + pl, r2, s->Np);
         s->downloadRows(s->aux.p + 2 * pl, r3, s->Np);
+    });
+}
+
+int bdg_sw2d_num_fields(const bdg_sw2d* s) { return s ? s->nf : -1; }
+
+int bdg_sw2d_set_state4(bdg_sw2d* s, const double* h, const double* hu, const double* hv, const double* hN) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_set_state4");
+        if (s->nf != 4) throw arg_error("bdg_sw2d_set_state4: the solver was created with 3 fields");
+        const double* f[4] = {h, hu, hv, hN};
+        s->use();
+        for (int c = 0; c < 4; ++c) {
+            if (!f[c]) throw arg_error("bdg_sw2d_set_state4: NULL field");
+            s->uploadRows(f[c], s->qcur + c * s->planeSize(), s->Np);
+        }
+        hipCheck(hipMemsetAsync(s->res.p, 0, s->res.n * sizeof(double), s->stream), "hipMemset");
+        s->stageCount = 0;
+        hipCheck(hipStreamSynchronize(s->stream), "set_state sync");
+    });
+}
+
+int bdg_sw2d_get_state4(bdg_sw2d* s, double* h, double* hu, double* hv, double* hN) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_get_state4");
+        if (s->nf != 4) throw arg_error("bdg_sw2d_get_state4: the solver was created with 3 fields");
+        double* f[4] = {h, hu, hv, hN};
+        s->use();
+        for (int c = 0; c < 4; ++c) {
+            if (!f[c]) throw arg_error("bdg_sw2d_get_state4: NULL field");
+            s->downloadRows(s->qcur + c * s->planeSize(), f[c], s->Np);
+        }
+    });
+}
+
+int bdg_sw2d_rhs4(bdg_sw2d* s, const double* h, const double* hu, const double* hv, const double* hN, double* r1,
+                  double* r2, double* r3, double* r4, int filter) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_rhs4");
+        if (s->nf != 4) throw arg_error("bdg_sw2d_rhs4: the solver was created with 3 fields");
+        const double* in[4] = {h, hu, hv, hN};
+        double* out[4] = {r1, r2, r3, r4};
+        s->use();
+        for (int c = 0; c < 4; ++c) {
+            if (!in[c] || !out[c]) throw arg_error("bdg_sw2d_rhs4: NULL field");
+            s->uploadRows(in[c], s->qalt + c * s->planeSize(), s->Np);
+        }
+        s->launchRhs(s->qalt, s->aux.p, filter != 0);
+        for (int c = 0; c < 4; ++c) s->downloadRows(s->aux.p + c * s->planeSize(), out[c], s->Np);
     });
 }
 
@@ -930,7 +1040,7 @@ int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const i
     });
 }
 
-int bdg_sw2d_halo_doubles_per_element(const bdg_sw2d* s) { return s ? 3 * s->Np : -1; }
+int bdg_sw2d_halo_doubles_per_element(const bdg_sw2d* s) { return s ? s->nf * s->Np : -1; }
 
 int bdg_sw2d_halo_pack(bdg_sw2d* s, void* send_buffer) {
     return guard([&] {
@@ -938,7 +1048,7 @@ int bdg_sw2d_halo_pack(bdg_sw2d* s, void* send_buffer) {
         if (s->numSend == 0) return;
         if (!send_buffer) throw arg_error("bdg_sw2d_halo_pack: buffer is NULL");
         s->use();
-        const int rows = 3 * s->Np;
+        const int rows = s->nf * s->Np;
         const long long n = static_cast<long long>(s->numSend) * rows;
         hipLaunchKernelGGL(bdg_dev::halo_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
                            s->stream, s->qcur, static_cast<double*>(send_buffer), s->sendSlots.p, s->numSend, rows,
@@ -954,7 +1064,7 @@ int bdg_sw2d_halo_unpack(bdg_sw2d* s, const void* recv_buffer) {
         if (ghosts == 0) return;
         if (!recv_buffer) throw arg_error("bdg_sw2d_halo_unpack: buffer is NULL");
         s->use();
-        const int rows = 3 * s->Np;
+        const int rows = s->nf * s->Np;
         const long long n = static_cast<long long>(ghosts) * rows;
         hipLaunchKernelGGL(bdg_dev::halo_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
                            s->stream, s->qcur, static_cast<const double*>(recv_buffer), s->numOwned, ghosts, rows,
@@ -976,6 +1086,7 @@ int bdg_sw2d_lserk4_stage_part(bdg_sw2d* s, double dt, int part) {
 int bdg_sw2d_rhs_resident(bdg_sw2d* s, double* r1, double* r2, double* r3) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_rhs_resident");
+        if (s->nf != 3) throw arg_error("bdg_sw2d_rhs_resident: three-field solvers only");
         if (!r1 || !r2 || !r3) throw arg_error("bdg_sw2d_rhs_resident: NULL output");
         s->use();
         const size_t pl = s->planeSize();
@@ -1025,7 +1136,7 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
         hipCheck(hipEventCreateWithFlags(&s->evPacked, hipEventDisableTiming), "hipEventCreate");
         hipCheck(hipEventCreateWithFlags(&s->evExchanged, hipEventDisableTiming), "hipEventCreate");
-        const size_t rows = 3 * static_cast<size_t>(s->Np);
+        const size_t rows = static_cast<size_t>(s->nf) * s->Np;
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
         s->scalarBuf.alloc(2, s->bytes);

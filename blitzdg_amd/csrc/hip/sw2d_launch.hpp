@@ -3,6 +3,7 @@
 // kernels build in parallel; the solver picks the table at run time.
 #pragma once
 #include "sw2d_affine_kernel.hpp"
+#include "sw2d_vd_kernel.hpp"
 #include "sw2d_kernels.hpp"
 
 namespace bdg_dev {
@@ -14,6 +15,9 @@ struct KernelTable {
     // affine-geometry fast path (no FILTER template: the filter is folded into the operators)
     int affineOpsDoubles;
     hipError_t (*stageAffine)(int mode, int variant, const StageParams& p, hipStream_t stream);
+    // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
+    int vdOpsDoubles;
+    hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);
     // per-block partial maxima (2 doubles per block of 256 elements)
     hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
                      double* partials, hipStream_t stream);

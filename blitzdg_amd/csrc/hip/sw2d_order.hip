@@ -111,6 +111,23 @@ hipError_t stageAffine(int mode, int variant, const StageParams& p, hipStream_t 
     }
 }
 
+template <int MODE>
+hipError_t launchVd(const StageParams& p, const VdParams& vp, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
+    hipLaunchKernelGGL((sw2d_stage_vd_kernel<kN, MODE>), dim3(grid), dim3(64 * vp.nf), 0, stream, p, vp);
+    return hipGetLastError();
+}
+
+hipError_t stageVd(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchVd<MODE_RHS>(p, vp, stream);
+    case MODE_LSERK: return launchVd<MODE_LSERK>(p, vp, stream);
+    case MODE_COMBINE: return launchVd<MODE_COMBINE>(p, vp, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t dt(const double* q, const double* fscale, const double* H, long long ld, int K, double g, double* partials,
               hipStream_t stream) {
     const unsigned grid = static_cast<unsigned>((K + kBlock - 1) / kBlock);
@@ -128,7 +145,8 @@ int fmaskOf(int f, int n) { return Elem<kN>::fmask(f, n); }
 // the device and then fail to resolve the host function pointers in).
 const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
-                                      AffineOps<kN>::DOUBLES, &stageAffine, &dt, &fmaskOf};
+                                      AffineOps<kN>::DOUBLES, &stageAffine, VdOps<kN>::DOUBLES, &stageVd, &dt,
+                                      &fmaskOf};
     return &table;
 }
 

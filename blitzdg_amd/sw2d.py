@@ -24,11 +24,26 @@ KEEP_ORDER = C.BDG_SW2D_KEEP_ORDER
 class Sw2dSolver:
     """Device-resident shallow-water DG solver (one HIP device, one stream)."""
 
-    def __init__(self, nodes=None, g=9.81, device=0, flags=0, tables=None):
+    def __init__(self, nodes=None, g=9.81, device=0, flags=0, tables=None, fields=3, sources=None):
         """Create from a ``pyblitzdg.TriangleNodesProvisioner`` (``nodes``) or from a dict of
         host tables (``tables``: order, Dr, Ds, Lift, rx, sx, ry, sy, nx, ny, Fscale, vmapP, mapW and
-        optionally vmapM, Filter)."""
+        optionally vmapM, Filter).
+
+        ``fields=4`` adds the passive tracer hN; ``sources=dict(zx=, zy=, f=, CD=)`` switches on the
+        Coriolis / drag / bed-slope terms of the reference's Python RHS (swhelpers/rhs.py:300-309;
+        ``f`` scalar or (Np, K) array). Both need ``tables`` (or a ``nodes`` object, whose tables are
+        then read through its DGContext2D)."""
         h = c_void_p()
+        self.fields = int(fields)
+        if nodes is not None and (self.fields != 3 or sources is not None):
+            ctx = nodes.dgContext()
+            tables = {k: getattr(ctx, k) for k in ("Dr", "Ds", "Lift", "rx", "sx", "ry", "sy", "nx", "ny", "Fscale",
+                                                   "vmapM", "vmapP")}
+            tables["order"] = ctx.order
+            tables["mapW"] = np.array(ctx.BCmap.get(3, []), dtype=np.int32)
+            filt = ctx.filter
+            tables["Filter"] = filt if np.any(filt) else None
+            nodes = None
         if nodes is not None:
             check(lib.bdg_sw2d_create_from_nodes(nodes._h, float(g), int(device), int(flags), byref(h)))
             _, self.Np, self.Nfp, self.K = nodes._dims()
@@ -51,11 +66,21 @@ class Sw2dSolver:
                 raise ValueError("vmapP must have 3*Nfp*K entries")
             filt = C.as_f64(t["Filter"], (Np, Np), "Filter") if t.get("Filter") is not None else None
             vmapM = C.as_i32(t["vmapM"]).reshape(-1) if t.get("vmapM") is not None else None
+            src = dict(sources) if sources is not None else None
+            zx = C.as_f64(src["zx"], (Np, K), "zx") if src and src.get("zx") is not None else None
+            zy = C.as_f64(src["zy"], (Np, K), "zy") if src and src.get("zy") is not None else None
+            fcor, fconst = None, 0.0
+            if src and src.get("f") is not None:
+                if np.ndim(src["f"]) == 0:
+                    fconst = float(src["f"])
+                else:
+                    fcor = C.as_f64(src["f"], (Np, K), "f")
             d = C.Sw2dDesc(order, K, C.ptr(arrs["Dr"]), C.ptr(arrs["Ds"]), C.ptr(arrs["Lift"]), C.ptr(filt),
                            C.ptr(arrs["rx"]), C.ptr(arrs["sx"]), C.ptr(arrs["ry"]), C.ptr(arrs["sy"]),
                            C.ptr(arrs["nx"]), C.ptr(arrs["ny"]), C.ptr(arrs["Fscale"]), C.ptr(vmapM),
                            C.ptr(arrs["vmapP"]), C.ptr(arrs["mapW"]), arrs["mapW"].size, float(g), int(device),
-                           int(flags))
+                           int(flags), self.fields, 1 if src is not None else 0, C.ptr(zx), C.ptr(zy), C.ptr(fcor),
+                           fconst, float(src.get("CD", 0.0)) if src else 0.0)
             check(lib.bdg_sw2d_create(byref(d), byref(h)))
             self.order, self.Np, self.Nfp, self.K = order, Np, order + 1, K
         else:
@@ -79,6 +104,21 @@ class Sw2dSolver:
     def getState(self):
         out = [np.empty((self.Np, self.K)) for _ in range(3)]
         check(lib.bdg_sw2d_get_state(self._h, *[C.ptr(o) for o in out]))
+        return tuple(out)
+
+    def setState4(self, h, hu, hv, hN):
+        f = [self._field(a, n) for a, n in zip((h, hu, hv, hN), ("h", "hu", "hv", "hN"))]
+        check(lib.bdg_sw2d_set_state4(self._h, *[C.ptr(a) for a in f]))
+
+    def getState4(self):
+        out = [np.empty((self.Np, self.K)) for _ in range(4)]
+        check(lib.bdg_sw2d_get_state4(self._h, *[C.ptr(o) for o in out]))
+        return tuple(out)
+
+    def computeRHS4(self, h, hu, hv, hN, filter=False):
+        f = [self._field(a, n) for a, n in zip((h, hu, hv, hN), ("h", "hu", "hv", "hN"))]
+        out = [np.empty((self.Np, self.K)) for _ in range(4)]
+        check(lib.bdg_sw2d_rhs4(self._h, *[C.ptr(a) for a in f], *[C.ptr(o) for o in out], int(bool(filter))))
         return tuple(out)
 
     def setBathymetry(self, H):

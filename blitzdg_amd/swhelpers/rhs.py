@@ -1,0 +1,37 @@
+"""``sw2dComputeRHS`` with the signature of the reference's swhelpers/rhs.py:178:
+
+    sw2dComputeRHS(h, hu, hv, hN, zx, zy, g, H, f, CD, ctx, vmapM, vmapP) -> (RHS1, RHS2, RHS3, RHS4)
+
+evaluated on the MI355X through the C ABI (4 fields: h, hu, hv and the tracer hN; Coriolis
+``f`` (scalar or (Np, K)), drag ``CD``, bed slope ``zx, zy``). ``H`` is accepted and, as in the
+reference (rhs.py:207-210, eta is computed but unused), does not enter the result. ``ctx`` is any
+object with the DGContext2D attributes the reference function reads (BCmap, nx, ny, rx, sx, ry,
+sy, Dr, Ds, numFacePoints, numElements, numFaces, Lift, Fscale).
+"""
+import numpy as np
+
+from ..sw2d import Sw2dSolver
+
+_cache = {}
+
+
+def _key(ctx, vmapM, vmapP, zx, zy, g, f, CD):
+    fkey = float(f) if np.ndim(f) == 0 else id(f)
+    return (id(ctx), id(vmapM), id(vmapP), id(zx), id(zy), float(g), fkey, float(CD))
+
+
+def sw2dComputeRHS(h, hu, hv, hN, zx, zy, g, H, f, CD, ctx, vmapM, vmapP):
+    key = _key(ctx, vmapM, vmapP, zx, zy, g, f, CD)
+    entry = _cache.get(key)
+    if entry is None:
+        Nfp = int(ctx.numFacePoints)
+        tables = {"order": Nfp - 1, "Dr": ctx.Dr, "Ds": ctx.Ds, "Lift": ctx.Lift, "rx": ctx.rx, "sx": ctx.sx,
+                  "ry": ctx.ry, "sy": ctx.sy, "nx": ctx.nx, "ny": ctx.ny, "Fscale": ctx.Fscale, "vmapM": vmapM,
+                  "vmapP": vmapP, "mapW": np.asarray(ctx.BCmap.get(3, []), dtype=np.int32)}
+        solver = Sw2dSolver(tables=tables, g=g, fields=4, sources={"zx": zx, "zy": zy, "f": f, "CD": CD})
+        # keep the keyed objects alive so ids are not recycled while the entry exists
+        entry = (solver, (ctx, vmapM, vmapP, zx, zy, f))
+        if len(_cache) >= 8:
+            _cache.pop(next(iter(_cache)))
+        _cache[key] = entry
+    return entry[0].computeRHS4(h, hu, hv, hN)

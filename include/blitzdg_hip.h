@@ -152,6 +152,15 @@ typedef struct bdg_sw2d_desc {
     double g;           /* gravitational acceleration                                 */
     int device;         /* HIP device ordinal                                         */
     int flags;          /* BDG_SW2D_* bits                                            */
+    /* ---- optional "variant D" physics of the reference's Python RHS (swhelpers/rhs.py:178-311);
+     * all zero / NULL gives variant A above. Straight-sided elements only. */
+    int num_fields;     /* 0 or 3: h, hu, hv;  4: + passive tracer hN (F4 = hN u, G4 = hN v)      */
+    int sources;        /* nonzero: RHS2 += f hv - CD|u|u - g h zx;  RHS3 -= f hu - CD|u|v;  RHS3 -= g h zy */
+    const double* zx;   /* (Np, K) bed slope or NULL (= 0)                            */
+    const double* zy;
+    const double* coriolis; /* (Np, K) Coriolis parameter f, or NULL: coriolis_const    */
+    double coriolis_const;
+    double drag;        /* CD                                                         */
 } bdg_sw2d_desc;
 
 #define BDG_SW2D_MAX_ORDER 8 /* 7 and 8: straight-sided (affine) geometry only */
@@ -180,6 +189,14 @@ int bdg_sw2d_set_bathymetry(bdg_sw2d* s, const double* H);
  * Does not disturb the resident state. filter != 0 applies Filter to the result. */
 int bdg_sw2d_rhs(bdg_sw2d* s, const double* h, const double* hu, const double* hv, double* rhs1,
                  double* rhs2, double* rhs3, int filter);
+
+/* Four-field forms for solvers created with num_fields = 4 (hN: tracer). The three-field
+ * functions above refuse such a solver and vice versa. */
+int bdg_sw2d_set_state4(bdg_sw2d* s, const double* h, const double* hu, const double* hv, const double* hN);
+int bdg_sw2d_get_state4(bdg_sw2d* s, double* h, double* hu, double* hv, double* hN);
+int bdg_sw2d_rhs4(bdg_sw2d* s, const double* h, const double* hu, const double* hv, const double* hN,
+                  double* rhs1, double* rhs2, double* rhs3, double* rhs4, int filter);
+int bdg_sw2d_num_fields(const bdg_sw2d* s);
 
 /* Resident time stepping (state stays in HBM). */
 int bdg_sw2d_step_lserk4(bdg_sw2d* s, double dt, int num_steps);          /* 5 fused stages per step */

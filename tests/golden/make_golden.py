@@ -114,6 +114,42 @@ def rhs_case(name, mesh, order, g=9.81):
           f"{max(abs(r1).max(), abs(r2).max(), abs(r3).max()):.6g}")
 
 
+def rhs4_case(name, mesh, order, g=9.81):
+    """Variant D: tracer + Coriolis (array f) + drag + bed slope, all non-trivial; output of the
+    reference's swhelpers.rhs.sw2dComputeRHS itself."""
+    import blitzdg_amd.pyblitzdg as dg
+    sys.path.insert(0, REF)
+    if not hasattr(np, "float"):
+        np.float = float
+    from swhelpers.rhs import sw2dComputeRHS
+
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    ctx = nodes.dgContext()
+    tabs = {k: getattr(ctx, k) for k in
+            ("Dr", "Ds", "Lift", "rx", "sx", "ry", "sy", "nx", "ny", "Fscale", "vmapM", "vmapP", "x", "y")}
+    tabs["Filter"] = ctx.filter
+    bcmap = ctx.BCmap
+    tabs["mapW"] = np.array(bcmap.get(3, []), dtype=np.int32)
+    x, y = tabs["x"], tabs["y"]
+    h, hu, hv = seeded_fields(x, y)
+    rng = np.random.default_rng(1)
+    hN = h * (1.0 + 0.3 * np.sin(2 * x) * np.cos(3 * y)) + 0.05 * rng.standard_normal(x.shape)
+    H = 10.0 - 0.5 * x + 0.25 * y * y
+    zx, zy = -0.5 + 0 * x, 0.5 * y
+    f = 1e-1 * (1.0 + 0.5 * y)
+    CD = 2.5e-2
+    ref_ctx = types.SimpleNamespace(BCmap=bcmap, nx=tabs["nx"], ny=tabs["ny"], rx=tabs["rx"], sx=tabs["sx"],
+                                    ry=tabs["ry"], sy=tabs["sy"], Dr=tabs["Dr"], Ds=tabs["Ds"],
+                                    numFacePoints=ctx.numFacePoints, numElements=ctx.numElements,
+                                    numFaces=ctx.numFaces, Lift=tabs["Lift"], Fscale=tabs["Fscale"])
+    r = sw2dComputeRHS(h, hu, hv, hN, zx, zy, g, H, f, CD, ref_ctx, tabs["vmapM"], tabs["vmapP"])
+    np.savez_compressed(os.path.join(HERE, f"sw2d_rhs4_{name}.npz"), order=order, g=g, h=h, hu=hu, hv=hv, hN=hN,
+                        H=H, zx=zx, zy=zy, f=f, CD=CD, rhs1=r[0], rhs2=r[1], rhs3=r[2], rhs4=r[3], **tabs)
+    print(f"sw2d_rhs4_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} |rhs|max="
+          f"{max(abs(a).max() for a in r):.6g}")
+
+
 def main():
     import blitzdg_amd.pyblitzdg as dg
     shutil.copyfile(os.path.join(REF, "input/coarse_box.msh"), os.path.join(HERE, "coarse_box.msh"))
@@ -128,6 +164,10 @@ def main():
     shuffled = dg.MeshManager()
     shuffled.buildBoxMesh(6, 5, shuffleSeed=12345)
     rhs_case("box6x5_shuffled_N4", shuffled, 4)
+    for order in (2, 4, 6):
+        rhs4_case(f"coarse_box_N{order}", coarse, order)
+    rhs4_case("box6x5_shuffled_N3", shuffled, 3)
+    rhs4_case("box2x2_N8", box, 8)
 
 
 if __name__ == "__main__":
