@@ -115,6 +115,7 @@ _SIGNATURES = {
     "bdg_sw2d_step_lserk4": (c_int, [_P, c_double, c_int]),
     "bdg_sw2d_lserk4_stages": (c_int, [_P, c_double, c_int]),
     "bdg_sw2d_step_rk2": (c_int, [_P, c_double, c_int, c_int]),
+    "bdg_sw2d_step_ssprk2": (c_int, [_P, c_double, c_int, c_int, c_double]),
     "bdg_sw2d_compute_dt": (c_int, [_P, c_double, POINTER(c_double), POINTER(c_double)]),
     "bdg_sw2d_run_adaptive": (c_int, [_P, c_double, c_double, c_int, c_int, POINTER(c_double),
                                       POINTER(c_double), POINTER(c_int)]),

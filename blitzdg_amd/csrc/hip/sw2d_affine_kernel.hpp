@@ -256,8 +256,8 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
             st_row(o + i * ld, k8, a * old1[i] + b * h[i] + c * R1[i]);
-            st_row(o + plane + i * ld, k8, a * old2[i] + b * hu[i] + c * R2[i]);
-            st_row(o + 2 * plane + i * ld, k8, a * old3[i] + b * hv[i] + c * R3[i]);
+            st_row(o + plane + i * ld, k8, sponge_relax(a * old2[i] + b * hu[i] + c * R2[i], p.sponge));
+            st_row(o + 2 * plane + i * ld, k8, sponge_relax(a * old3[i] + b * hv[i] + c * R3[i], p.sponge));
         }
     }
 }
@@ -458,8 +458,8 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_stage_affine_stream_kernel(co
                         st_row(o + 2 * plane + i * ld, k8, q3[t] + b * n3);
                     } else {
                         st_row(o + i * ld, k8, a * o1[t] + b * q1[t] + c * R1[i]);
-                        st_row(o + plane + i * ld, k8, a * o2[t] + b * q2[t] + c * R2[i]);
-                        st_row(o + 2 * plane + i * ld, k8, a * o3[t] + b * q3[t] + c * R3[i]);
+                        st_row(o + plane + i * ld, k8, sponge_relax(a * o2[t] + b * q2[t] + c * R2[i], p.sponge));
+                        st_row(o + 2 * plane + i * ld, k8, sponge_relax(a * o3[t] + b * q3[t] + c * R3[i], p.sponge));
                     }
                 }
             }
@@ -641,7 +641,9 @@ __global__ __launch_bounds__(FIELDS == 3 ? 256 : 192, 2) void sw2d_stage_affine_
                             st_row(p.res + fo + i * ld, k8, n1);
                             st_row(p.qout + fo + i * ld, k8, q1[t] + b * n1);
                         } else {
-                            st_row(p.qout + fo + i * ld, k8, a * o1[t] + b * q1[t] + cc * R[q][i]);
+                            const double val = a * o1[t] + b * q1[t] + cc * R[q][i];
+                            const bool momentum = (FIELDS == 3 ? q : c) == 1 || (FIELDS == 3 ? q : c) == 2;
+                            st_row(p.qout + fo + i * ld, k8, momentum ? sponge_relax(val, p.sponge) : val);
                         }
                     }
                 }

@@ -435,6 +435,20 @@ struct bdg_sw2d {
         std::swap(qcur, qalt);
     }
 
+    // SSP-RK2 (Heun) of the reference's variant-B driver (src/sw2d/main.cpp:211-235), sponge optional:
+    //   q1 = sponge(q + dt R(q));   q = sponge(1/2 (q + q1 + dt R(q1)))
+    void launchSspRk2Step(double dt, bool filter, double spongeCoeff) {
+        bdg_dev::StageParams p = baseParams();
+        p.sponge = spongeCoeff;
+        p.qin = qcur; p.qbase = qcur; p.qout = aux.p;
+        p.ca = 1.0; p.cb = 0.0; p.cc = dt;
+        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
+        p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
+        p.ca = 0.5; p.cb = 0.5; p.cc = 0.5 * dt;
+        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
+        std::swap(qcur, qalt);
+    }
+
     // Returns {max |Fscale|*spd, max |eta|}; NaN if any entry is NaN.
     void reduceDt(double out[2]) {
         const int nblocks = (numOwned + 255) / 256;
@@ -951,6 +965,15 @@ int bdg_sw2d_step_rk2(bdg_sw2d* s, double dt, int num_steps, int filter) {
         if (num_steps < 0) throw arg_error("bdg_sw2d_step_rk2: num_steps < 0");
         s->use();
         for (int i = 0; i < num_steps; ++i) s->launchRk2Step(dt, filter != 0);
+    });
+}
+
+int bdg_sw2d_step_ssprk2(bdg_sw2d* s, double dt, int num_steps, int filter, double sponge_coeff) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_step_ssprk2");
+        if (num_steps < 0) throw arg_error("bdg_sw2d_step_ssprk2: num_steps < 0");
+        s->use();
+        for (int i = 0; i < num_steps; ++i) s->launchSspRk2Step(dt, filter != 0, sponge_coeff);
     });
 }
 

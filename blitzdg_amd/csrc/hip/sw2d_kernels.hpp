@@ -70,7 +70,14 @@ struct StageParams {
     double g;
     double ca, cb, cc;
     double one;          // 1.0 (run-time constant used to stop value reuse across phases)
+    double sponge;       // MODE_COMBINE: momentum relaxation x /= (1 + sponge x^2) after the update (0: off)
 };
+
+// Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):
+// hu /= (1 + sigma hu^2), applied to the momentum components after a stage update.
+__device__ __forceinline__ double sponge_relax(double x, double sigma) {
+    return sigma != 0.0 ? x / (1.0 + sigma * x * x) : x;
+}
 
 template <int N, int MODE, bool FILTER>
 __global__ __launch_bounds__(256) void sw2d_stage_kernel(const StageParams p) {
@@ -258,8 +265,8 @@ __global__ __launch_bounds__(256) void sw2d_stage_kernel(const StageParams p) {
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
             o[i * ld] = a * qb[i * ld] + b * h[i] + c * R1[i];
-            o[plane + i * ld] = a * qb[plane + i * ld] + b * hu[i] + c * R2[i];
-            o[2 * plane + i * ld] = a * qb[2 * plane + i * ld] + b * hv[i] + c * R3[i];
+            o[plane + i * ld] = sponge_relax(a * qb[plane + i * ld] + b * hu[i] + c * R2[i], p.sponge);
+            o[2 * plane + i * ld] = sponge_relax(a * qb[2 * plane + i * ld] + b * hv[i] + c * R3[i], p.sponge);
         }
     }
 }

@@ -182,7 +182,8 @@ __global__ __launch_bounds__(256, 2) void sw2d_stage_vd_kernel(const StageParams
                         st_row(p.res + fo + i * ld, k8, n1);
                         st_row(p.qout + fo + i * ld, k8, q1[t] + b * n1);
                     } else {
-                        st_row(p.qout + fo + i * ld, k8, a * o1[t] + b * q1[t] + cc * R[i]);
+                        const double val = a * o1[t] + b * q1[t] + cc * R[i];
+                        st_row(p.qout + fo + i * ld, k8, (c == 1 || c == 2) ? sponge_relax(val, p.sponge) : val);
                     }
                 }
             }

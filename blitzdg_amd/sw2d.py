@@ -142,6 +142,10 @@ class Sw2dSolver:
     def stepRK2(self, dt, nsteps=1, filter=True):
         check(lib.bdg_sw2d_step_rk2(self._h, float(dt), int(nsteps), int(bool(filter))))
 
+    def stepSSPRK2(self, dt, nsteps=1, filter=False, sponge=0.0):
+        """Heun steps of the reference's variant-B driver (src/sw2d/main.cpp:211-235)."""
+        check(lib.bdg_sw2d_step_ssprk2(self._h, float(dt), int(nsteps), int(bool(filter)), float(sponge)))
+
     def computeDt(self, CFL):
         """(dt, max|eta|); raises NumericalInstability on NaN or |eta| > 1e8."""
         dt, em = c_double(), c_double()

@@ -202,6 +202,10 @@ int bdg_sw2d_num_fields(const bdg_sw2d* s);
 int bdg_sw2d_step_lserk4(bdg_sw2d* s, double dt, int num_steps);          /* 5 fused stages per step */
 int bdg_sw2d_lserk4_stages(bdg_sw2d* s, double dt, int num_stages);       /* stage i = count % 5      */
 int bdg_sw2d_step_rk2(bdg_sw2d* s, double dt, int num_steps, int filter); /* midpoint RK2            */
+/* SSP-RK2 (Heun) of the variant-B driver, reference src/sw2d/main.cpp:211-235:
+ * q1 = sp(q + dt R(q)); q = sp((q + q1 + dt R(q1))/2), sp(x) = x/(1 + sponge_coeff x^2) on hu, hv
+ * (sponge_coeff = 0: plain Heun). */
+int bdg_sw2d_step_ssprk2(bdg_sw2d* s, double dt, int num_steps, int filter, double sponge_coeff);
 /* dt = CFL / ((N+1)^2 * 0.5 * max_i |Fscale_i| * (|u|+sqrt(g h))[vmapM_i]); also returns
  * max|eta| (or max|h|) and BDG_ERR_UNSTABLE on NaN / > 1e8. */
 int bdg_sw2d_compute_dt(bdg_sw2d* s, double cfl, double* dt, double* eta_max);

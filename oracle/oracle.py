@@ -106,6 +106,17 @@ class Sw2dOracle:
                 raise RuntimeError(f"oracle_sw2d_step_rk2 failed ({rc})")
         return h, hu, hv
 
+    def step_ssprk2(self, h, hu, hv, dt, nsteps=1, filter=False, sponge=0.0):
+        """Heun steps with the variant-B sponge (src/sw2d/main.cpp:211-235); returns new (h, hu, hv)."""
+        h, hu, hv = [f.copy() for f in self._fields(h, hu, hv)]
+        c = self._ctx()
+        for _ in range(nsteps):
+            rc = self._lib.oracle_sw2d_step_ssprk2(byref(c), _p(h), _p(hu), _p(hv), c_double(dt), int(bool(filter)),
+                                                   c_double(sponge))
+            if rc:
+                raise RuntimeError(f"oracle_sw2d_step_ssprk2 failed ({rc})")
+        return h, hu, hv
+
     def lserk4_stages(self, h, hu, hv, res, dt, first, num_stages):
         """Runs LSERK4 stages in place on copies; returns (h, hu, hv, res)."""
         h, hu, hv = [f.copy() for f in self._fields(h, hu, hv)]

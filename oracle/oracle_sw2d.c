@@ -247,6 +247,38 @@ int oracle_sw2d_step_rk2(const oracle_sw2d_ctx* c, double* h, double* hu, double
     return rc;
 }
 
+/* One SSP-RK2 (Heun) step with the sponge relaxation of the variant-B driver, in place
+ * (src/sw2d/main.cpp:211-235): q1 = q + dt R(q); hu1,hv1 /= 1 + s x^2; q = (q + q1 + dt R(q1))/2; sponge. */
+int oracle_sw2d_step_ssprk2(const oracle_sw2d_ctx* c, double* h, double* hu, double* hv, double dt, int filter,
+                            double sponge) {
+    const size_t nT = (size_t)c->Np * c->K;
+    double* w = (double*)malloc(sizeof(double) * 6 * nT);
+    if (!w) return 1;
+    double *R1 = w, *R2 = w + nT, *R3 = w + 2 * nT, *h1 = w + 3 * nT, *hu1 = w + 4 * nT, *hv1 = w + 5 * nT;
+    int rc = filter ? oracle_sw2d_rhs_filtered(c, h, hu, hv, R1, R2, R3) : oracle_sw2d_rhs(c, h, hu, hv, R1, R2, R3);
+    if (!rc) {
+        for (size_t i = 0; i < nT; ++i) {
+            h1[i] = h[i] + dt * R1[i];
+            hu1[i] = hu[i] + dt * R2[i];
+            hv1[i] = hv[i] + dt * R3[i];
+            hu1[i] /= (1.0 + sponge * hu1[i] * hu1[i]);
+            hv1[i] /= (1.0 + sponge * hv1[i] * hv1[i]);
+        }
+        rc = filter ? oracle_sw2d_rhs_filtered(c, h1, hu1, hv1, R1, R2, R3)
+                    : oracle_sw2d_rhs(c, h1, hu1, hv1, R1, R2, R3);
+    }
+    if (!rc)
+        for (size_t i = 0; i < nT; ++i) {
+            h[i] = 0.5 * (h[i] + h1[i] + dt * R1[i]);
+            hu[i] = 0.5 * (hu[i] + hu1[i] + dt * R2[i]);
+            hv[i] = 0.5 * (hv[i] + hv1[i] + dt * R3[i]);
+            hu[i] /= (1.0 + sponge * hu[i] * hu[i]);
+            hv[i] /= (1.0 + sponge * hv[i] * hv[i]);
+        }
+    free(w);
+    return rc;
+}
+
 /* num_stages LSERK4 stages starting at stage index `first` (mod 5), in place:
  *   res = a_i res + dt RHS(q);  q += b_i res        (src/advec1d/main.cpp:92-102) */
 int oracle_sw2d_lserk4_stages(const oracle_sw2d_ctx* c, double* h, double* hu, double* hv, double* res1, double* res2,

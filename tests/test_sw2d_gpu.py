@@ -448,3 +448,26 @@ def test_tracer_only_equals_three_field_solver(coarse_mesh):
     scale = max(np.abs(x).max() for x in r3)
     assert max(np.abs(a - b).max() for a, b in zip(r4[:3], r3)) / scale < RHS_TOL
     assert np.abs(r4[3] - 0.25 * r4[0]).max() / scale < RHS_TOL
+
+
+@pytest.mark.parametrize("order,flags", [(3, 0), (3, sw2d.NODAL_GEOMETRY), (6, 0), (8, 0)])
+def test_ssprk2_with_sponge_vs_oracle(order, flags):
+    """Heun stepping of the reference's variant-B driver (src/sw2d/main.cpp:211-235) including
+    the sponge relaxation hu /= (1 + sigma hu^2), on every kernel family."""
+    m = dg.MeshManager()
+    m.buildBoxMesh(9, 7, shuffleSeed=4)
+    nodes = dg.TriangleNodesProvisioner(order, m)
+    nodes.buildFilter(0.9 * order, order)
+    t = tables_from_nodes(nodes)
+    o = oracle_from(t)
+    h, hu, hv = seeded_fields(t["x"], t["y"])
+    hu, hv = 20 * hu, 20 * hv  # make the sponge matter
+    s = sw2d.Sw2dSolver(nodes=nodes, flags=flags)
+    dt = 0.3 * o.dt(h, hu, hv, 0.65, order)
+    for filt, sponge in ((False, 0.0), (True, 0.05)):
+        s.setState(h, hu, hv)
+        s.stepSSPRK2(dt, 4, filter=filt, sponge=sponge)
+        ref = o.step_ssprk2(h, hu, hv, dt, 4, filter=filt, sponge=sponge)
+        for a, b in zip(s.getState(), ref):
+            assert relmax(a, b) < STATE_TOL
+    assert np.abs(ref[1] - o.step_ssprk2(h, hu, hv, dt, 4, filter=True, sponge=0.0)[1]).max() > 1e-6
