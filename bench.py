@@ -157,7 +157,7 @@ def run_single(args):
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_elem * K, "kernel_ms": ms_per_launch,
                      "measured_stream_triad_GBps": triad, "same_access_pattern_no_compute_ms": probe_ms,
-                     "kernel": ("sw2d_stage_affine_fieldsplit_kernel" if ORDER > 6 else "sw2d_stage_affine_kernel") + f"<{ORDER}, MODE_LSERK>" if solver.usesAffineGeometry else f"sw2d_stage_kernel<{ORDER}, MODE_LSERK, false>"},
+                     "kernel": ("sw2d_stage_mfma_kernel" if ORDER > 5 else "sw2d_stage_affine_kernel") + f"<{ORDER}, MODE_LSERK>" if solver.usesAffineGeometry else f"sw2d_stage_kernel<{ORDER}, MODE_LSERK, false>"},
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(ORDER)

@@ -243,6 +243,7 @@ struct bdg_sw2d {
     size_t bytes = 0;
     DevBuf<double> qA, qB, res, aux, geo, fgeo, ops, Hbuf, stage, partials, red2;
     DevBuf<double> ageo, opsAffine, opsAffineFiltered; // affine-geometry fast path
+    DevBuf<double> opsMfma, opsMfmaFiltered;           // same operators in MFMA A-operand layout
     bool affine = false;
     // variant D (reference swhelpers/rhs.py:178-311): optional tracer field and source terms
     int nf = 3;
@@ -250,7 +251,7 @@ struct bdg_sw2d {
     bdg_dev::VdParams vd{};
     DevBuf<double> zxBuf, zyBuf, fcorBuf, opsVd, opsVdFiltered;
     int affineVariant = 0; // 0: unrolled, register-resident state; 2/3: unrolled, streamed state at 2/3 waves
-                           // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane
+                           // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane; 5: matrix cores (MFMA f64)
     DevBuf<int> vmapP, perm, istage, sendSlots;
     int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
     // native halo exchange (RCCL over xGMI): one send and one receive range per neighbour rank
@@ -323,6 +324,9 @@ struct bdg_sw2d {
         if (variantD) {
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
             hipCheck(kt->stageVd(mode, p, vd, stream), what);
+        } else if (affine && affineVariant == 5) {
+            p.opsAffine = filter ? opsMfmaFiltered.p : opsMfma.p;
+            hipCheck(kt->stageMfma(mode, p, stream), what);
         } else if (affine) {
             p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
             hipCheck(kt->stageAffine(mode, affineVariant, p, stream), what);
@@ -679,12 +683,12 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->uploadRows(d.Fscale, s->fscaleNodal, NFN);
 
     // ---- affine fast path: one metric value per element, one normal/scale per face
-    // Measured on MI355X: the fully unrolled kernel wins up to N=5; from N=6 on its
-    // basic block outgrows the register files and the rolled one-field-per-wave kernel is faster.
-    s->affineVariant = s->N <= 5 ? 0 : 1;
+    // Measured on MI355X: the fully unrolled vector kernel wins up to N=5; from
+    // N=6 on its basic block outgrows the register files and the matrix-core kernel is fastest.
+    s->affineVariant = s->N <= 5 ? 0 : 5;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 4) s->affineVariant = v;
+        if (v >= 0 && v <= 5) s->affineVariant = v;
     }
     if (s->affine) {
         s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);
@@ -703,10 +707,38 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
         s->opsAffine.alloc(plain.size(), s->bytes);
         hipCheck(hipMemcpy(s->opsAffine.p, plain.data(), plain.size() * sizeof(double), hipMemcpyHostToDevice),
                  "affine ops upload");
+        // the same operators as zero-padded 16x4 MFMA A tiles: lane l of tile (r, t) holds A[16r + (l&15)][4t + (l>>4)]
+        auto mfmaImage = [&](const double* Dr, const double* Ds, const double* Lift) {
+            const int MT = kt->mfmaMT, KV = kt->mfmaKV, KS = kt->mfmaKS;
+            std::vector<double> img(static_cast<size_t>(kt->mfmaOpsDoubles), 0.0);
+            auto fill = [&](size_t off, const double* A, int cols, int KT) {
+                for (int r = 0; r < MT; ++r)
+                    for (int t = 0; t < KT; ++t)
+                        for (int l = 0; l < 64; ++l) {
+                            const int i = 16 * r + (l & 15), k = 4 * t + (l >> 4);
+                            if (i < Np && k < cols) img[off + (static_cast<size_t>(r) * KT + t) * 64 + l] = A[i * cols + k];
+                        }
+            };
+            fill(0, Dr, Np, KV);
+            fill(static_cast<size_t>(MT) * KV * 64, Ds, Np, KV);
+            fill(static_cast<size_t>(2) * MT * KV * 64, Lift, NFN, KS);
+            return img;
+        };
+        {
+            const std::vector<double> img = mfmaImage(d.Dr, d.Ds, d.Lift);
+            s->opsMfma.alloc(img.size(), s->bytes);
+            hipCheck(hipMemcpy(s->opsMfma.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice), "mfma ops upload");
+        }
         if (d.Filter) {
             // Filter * (Dr, Ds, Lift): the filtered RHS of an affine element is linear in these.
             const std::vector<double> FDr = matmulHost(d.Filter, d.Dr, Np, Np), FDs = matmulHost(d.Filter, d.Ds, Np, Np),
                                       FL = matmulHost(d.Filter, d.Lift, Np, NFN);
+            {
+                const std::vector<double> img = mfmaImage(FDr.data(), FDs.data(), FL.data());
+                s->opsMfmaFiltered.alloc(img.size(), s->bytes);
+                hipCheck(hipMemcpy(s->opsMfmaFiltered.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice),
+                         "filtered mfma ops upload");
+            }
             const std::vector<double> filt = affineOpsImage(FDr.data(), FDs.data(), FL.data(), Np, NFN);
             s->opsAffineFiltered.alloc(filt.size(), s->bytes);
             hipCheck(hipMemcpy(s->opsAffineFiltered.p, filt.data(), filt.size() * sizeof(double),

@@ -4,6 +4,7 @@
 #pragma once
 #include "sw2d_affine_kernel.hpp"
 #include "sw2d_vd_kernel.hpp"
+#include "sw2d_mfma_kernel.hpp"
 #include "sw2d_kernels.hpp"
 
 namespace bdg_dev {
@@ -15,6 +16,9 @@ struct KernelTable {
     // affine-geometry fast path (no FILTER template: the filter is folded into the operators)
     int affineOpsDoubles;
     hipError_t (*stageAffine)(int mode, int variant, const StageParams& p, hipStream_t stream);
+    // matrix-core path (v_mfma_f64_16x16x4_f64), straight-sided elements; needs ldsBytes of dynamic LDS
+    int mfmaOpsDoubles, mfmaMT, mfmaKV, mfmaKS;
+    hipError_t (*stageMfma)(int mode, const StageParams& p, hipStream_t stream);
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);

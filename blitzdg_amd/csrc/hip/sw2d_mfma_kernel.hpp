@@ -1,0 +1,221 @@
+// sw2d_mfma_kernel.hpp -- fused RHS + stage update with the operator applies on the matrix cores
+// (v_mfma_f64_16x16x4_f64), straight-sided elements, any order.
+//
+// Same mathematics as sw2d_stage_affine_kernel (reference src/sw2d-simple/main.cpp:181-356 + stage
+// update): per element  R_c = Dr' a_c + Ds' b_c + Lift' s_c  with the contravariant fluxes
+// a_c = -(rx F_c + ry G_c), b_c = -(sx F_c + sy G_c) and the scaled Lax-Friedrichs jumps s_c.
+// Here that is a batched GEMM: for a tile of 16 elements,
+//     R_c (Np x 16)  =  [Dr' | Ds' | Lift'] (Np x (2Np + 3Nfp))  *  [a_c ; b_c ; s_c] ((2Np + 3Nfp) x 16)
+// evaluated with 16x16x4 f64 MFMAs. A wavefront owns 16 elements; lane l = (q = l>>4, j = l&15)
+// works on element j of the tile and on the nodes congruent to q mod 4. That is exactly the B-operand
+// layout of the instruction (B[k = l>>4][col = l&15]), so the pointwise physics is computed directly
+// in operand layout -- no cross-lane traffic, no redundancy -- and the C/D layout
+// (col = l&15, row = (l>>4) + 4*reg) hands every lane the output nodes q, q+4, q+8, ... of its own
+// element for the stage update. A operands (operator tiles, zero padded to 16 x 4) are staged once
+// per workgroup in LDS in lane order and read with one conflict-free ds_read_b64 per MFMA.
+// Memory accesses are 128-byte row segments (16 elements x 8 B), four rows per wave instruction.
+// Only the per-face maximum of the wave speed crosses lanes (two xor-shuffles per face).
+#pragma once
+#include "sw2d_affine_kernel.hpp"
+
+namespace bdg_dev {
+
+typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
+
+#ifndef BDG_MFMA_WAVES
+#define BDG_MFMA_WAVES 1 // waves per SIMD the register budget is set for (2 spills at N >= 6)
+#endif
+
+template <int N>
+struct MfmaOps {
+    using E = Elem<N>;
+    static constexpr int MT = (E::Np + 15) / 16;   // 16-row tiles of output nodes
+    static constexpr int KV = (E::Np + 3) / 4;     // 4-deep steps over input nodes
+    static constexpr int KS = (E::NFN + 3) / 4;    // 4-deep steps over face nodes
+    // image: [matrix: Dr', Ds'][r][t][64] then [Lift'][r][t][64]; entry lane l = A[16r + (l&15)][4t + (l>>4)]
+    static constexpr int OFF_DR = 0;
+    static constexpr int OFF_DS = MT * KV * 64;
+    static constexpr int OFF_LIFT = 2 * MT * KV * 64;
+    static constexpr int DOUBLES = OFF_LIFT + MT * KS * 64;
+};
+
+template <int N, int MODE>
+__global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(const StageParams p) {
+    using E = Elem<N>;
+    using O = MfmaOps<N>;
+    constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN, MT = O::MT, KV = O::KV, KS = O::KS;
+
+    extern __shared__ double sOps[];
+    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    // XCD-aware, contiguous chunks of tiles per wave (neighbouring tiles share an L2)
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const unsigned blk = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const unsigned wave = blk * 4u + (threadIdx.x >> 6), nwaves = nwg * 4u;
+    const unsigned ntiles = (static_cast<unsigned>(p.kend - p.kbegin) + 15u) / 16u;
+    const unsigned perWave = (ntiles + nwaves - 1u) / nwaves;
+    const unsigned tileEnd = min(ntiles, (wave + 1u) * perWave);
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
+    const double* __restrict__ qin = p.qin;
+    const double* __restrict__ ag = p.ageo;
+    const double g = p.g, halfg = 0.5 * p.g;
+    const unsigned kLast = static_cast<unsigned>(p.kend) - 1u;
+
+    for (unsigned tile = wave * perWave; tile < tileEnd; ++tile) {
+        const unsigned kTrue = static_cast<unsigned>(p.kbegin) + tile * 16u + j;
+        const bool live = kTrue <= kLast;
+        const unsigned k = live ? kTrue : kLast; // padding lanes recompute the last element, store nothing
+        const unsigned k8 = k * 8u, k4 = k * 4u;
+
+        mfma_acc_t acc[3][MT];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) acc[c][r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+
+        // ---- volume term: k-steps of 4 input nodes, this lane supplies node m = 4t + q
+        {
+            const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
+                         sy = ld_row(ag + 3 * ld, k8);
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const int m = 4 * t + static_cast<int>(q);
+                double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
+                if (m < Np) {
+                    const double h = ld_row(qin + m * ld, k8), hu = ld_row(qin + plane + m * ld, k8),
+                                 hv = ld_row(qin + 2 * plane + m * ld, k8);
+                    const double r = fast_rcp(h);
+                    const double u = hu * r, v = hv * r;
+                    const double pr = halfg * h * h;
+                    const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
+                    a1 = -(rx * hu + ry * hv); b1 = -(sx * hu + sy * hv);
+                    a2 = -(rx * F2 + ry * G2); b2 = -(sx * F2 + sy * G2);
+                    a3 = -(rx * G2 + ry * G3); b3 = -(sx * G2 + sy * G3);
+                }
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    const double Adr = sOps[O::OFF_DR + (r * KV + t) * 64 + lane];
+                    const double Ads = sOps[O::OFF_DS + (r * KV + t) * 64 + lane];
+                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a1, acc[0][r], 0, 0, 0);
+                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a2, acc[1][r], 0, 0, 0);
+                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a3, acc[2][r], 0, 0, 0);
+                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b1, acc[0][r], 0, 0, 0);
+                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b2, acc[1][r], 0, 0, 0);
+                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b3, acc[2][r], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- surface term: k-steps of 4 face nodes, this lane supplies face node jf = 4t + q
+        {
+            double e1[KS], e2[KS], e3[KS], d1[KS], d2[KS], d3[KS], spd[KS];
+            double lamF[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const int jf = 4 * t + static_cast<int>(q);
+                e1[t] = e2[t] = e3[t] = d1[t] = d2[t] = d3[t] = 0.0;
+                spd[t] = 0.0;
+                if (jf < NFN) {
+                    const int f = jf / Nfp, n = jf - f * Nfp, m = fmask_rt<N>(f, n);
+                    const double nxf = ld_row(ag + (4 + f) * ld, k8), nyf = ld_row(ag + (7 + f) * ld, k8);
+                    const int id = ld_row(p.vmapP + jf * ld, k4);
+                    const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
+                                 hvM = ld_row(qin + 2 * plane + m * ld, k8);
+                    const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
+                    const double hq = ld_row(qin, o8);
+                    double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
+                    if (id < 0) { // reflective wall: no normal flow
+                        const double un = huM * nxf + hvM * nyf;
+                        huq = huM - 2 * nxf * un;
+                        hvq = hvM - 2 * nyf * un;
+                    }
+                    const double rM = fast_rcp(hM), rP = fast_rcp(hq);
+                    const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
+                    const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                    const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                    spd[t] = fmax(spdM, spdP);
+                    const double prM = halfg * hM * hM, prP = halfg * hq * hq;
+                    const double F2M = huM * uM + prM, G2M = huM * vM, G3M = hvM * vM + prM;
+                    const double F2P = huq * uP + prP, G2P = huq * vP, G3P = hvq * vP + prP;
+                    d1[t] = hM - hq; d2[t] = huM - huq; d3[t] = hvM - hvq;
+                    e1[t] = d2[t] * nxf + d3[t] * nyf;
+                    e2[t] = (F2M - F2P) * nxf + (G2M - G2P) * nyf;
+                    e3[t] = (G2M - G2P) * nxf + (G3M - G3P) * nyf;
+                    lamF[0] = f == 0 ? fmax(lamF[0], spd[t]) : lamF[0];
+                    lamF[1] = f == 1 ? fmax(lamF[1], spd[t]) : lamF[1];
+                    lamF[2] = f == 2 ? fmax(lamF[2], spd[t]) : lamF[2];
+                }
+            }
+            // per-face maximum over the face's nodes: they sit in the 4 lanes (q) of this element
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                lamF[f] = fmax(lamF[f], __shfl_xor(lamF[f], 16));
+                lamF[f] = fmax(lamF[f], __shfl_xor(lamF[f], 32));
+            }
+            const double hf0 = 0.5 * ld_row(ag + 10 * ld, k8), hf1 = 0.5 * ld_row(ag + 11 * ld, k8),
+                         hf2 = 0.5 * ld_row(ag + 12 * ld, k8);
+#pragma unroll
+            for (int t = 0; t < KS; ++t) {
+                const int jf = 4 * t + static_cast<int>(q);
+                const int f = jf / Nfp;
+                const double lam = f == 0 ? lamF[0] : (f == 1 ? lamF[1] : lamF[2]);
+                const double hfs = jf < NFN ? (f == 0 ? hf0 : (f == 1 ? hf1 : hf2)) : 0.0;
+                const double s1 = hfs * (e1[t] - lam * d1[t]);
+                const double s2 = hfs * (e2[t] - lam * d2[t]);
+                const double s3 = hfs * (e3[t] - lam * d3[t]);
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    const double Al = sOps[O::OFF_LIFT + (r * KS + t) * 64 + lane];
+                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s1, acc[0][r], 0, 0, 0);
+                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s2, acc[1][r], 0, 0, 0);
+                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s3, acc[2][r], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- stage update / output: this lane holds output nodes i = 16r + q + 4*reg of its element
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const long long fo = static_cast<long long>(c) * plane;
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    double oldv[4], qv[4];
+                    if constexpr (MODE != MODE_RHS) {
+                        const double* __restrict__ base2 = ((MODE == MODE_LSERK) ? p.res : p.qbase) + fo;
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int i = 16 * r + static_cast<int>(q) + 4 * reg;
+                            if (i < Np) {
+                                qv[reg] = ld_row(qin + fo + i * ld, k8);
+                                oldv[reg] = ld_row(base2 + i * ld, k8);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = 16 * r + static_cast<int>(q) + 4 * reg;
+                        if (i < Np) {
+                            const double R = acc[c][r][reg];
+                            if constexpr (MODE == MODE_RHS) {
+                                st_row(p.rhs + fo + i * ld, k8, R);
+                            } else if constexpr (MODE == MODE_LSERK) {
+                                const double n1 = p.ca * oldv[reg] + p.cc * R;
+                                st_row(p.res + fo + i * ld, k8, n1);
+                                st_row(p.qout + fo + i * ld, k8, qv[reg] + p.cb * n1);
+                            } else {
+                                const double val = p.ca * oldv[reg] + p.cb * qv[reg] + p.cc * R;
+                                st_row(p.qout + fo + i * ld, k8, c == 0 ? val : sponge_relax(val, p.sponge));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+} // namespace bdg_dev
