@@ -244,6 +244,7 @@ struct bdg_sw2d {
     DevBuf<double> qA, qB, res, aux, geo, fgeo, ops, Hbuf, stage, partials, red2;
     DevBuf<double> ageo, opsAffine, opsAffineFiltered; // affine-geometry fast path
     DevBuf<double> opsMfma, opsMfmaFiltered;           // same operators in MFMA A-operand layout
+    DevBuf<double> opsMfma2, opsMfma2Filtered;         // ... with the lift tiles padded per face
     bool affine = false;
     // variant D (reference swhelpers/rhs.py:178-311): optional tracer field and source terms
     int nf = 3;
@@ -251,7 +252,8 @@ struct bdg_sw2d {
     bdg_dev::VdParams vd{};
     DevBuf<double> zxBuf, zyBuf, fcorBuf, opsVd, opsVdFiltered;
     int affineVariant = 0; // 0: unrolled, register-resident state; 2/3: unrolled, streamed state at 2/3 waves
-                           // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane; 5: matrix cores (MFMA f64)
+                           // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane; 5: matrix cores (MFMA f64),
+                           // whole tile unrolled; 6: matrix cores, face-by-face / chunked schedule at 2 waves per SIMD
     DevBuf<int> vmapP, perm, istage, sendSlots;
     int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
     // native halo exchange (RCCL over xGMI): one send and one receive range per neighbour rank
@@ -327,6 +329,9 @@ struct bdg_sw2d {
         } else if (affine && affineVariant == 5) {
             p.opsAffine = filter ? opsMfmaFiltered.p : opsMfma.p;
             hipCheck(kt->stageMfma(mode, p, stream), what);
+        } else if (affine && affineVariant == 6) {
+            p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
+            hipCheck(kt->stageMfma2(mode, p, stream), what);
         } else if (affine) {
             p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
             hipCheck(kt->stageAffine(mode, affineVariant, p, stream), what);
@@ -685,10 +690,10 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     // ---- affine fast path: one metric value per element, one normal/scale per face
     // Measured on MI355X: the fully unrolled vector kernel wins up to N=5; from
     // N=6 on its basic block outgrows the register files and the matrix-core kernel is fastest.
-    s->affineVariant = s->N <= 5 ? 0 : 5;
+    s->affineVariant = s->N <= 5 ? 0 : 6;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 5) s->affineVariant = v;
+        if (v >= 0 && v <= 6) s->affineVariant = v;
     }
     if (s->affine) {
         s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);
@@ -724,6 +729,28 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
             fill(static_cast<size_t>(2) * MT * KV * 64, Lift, NFN, KS);
             return img;
         };
+        // face-by-face variant: lift tile (r, f, tf), lane l = Lift[16r + (l&15)][f*Nfp + 4tf + (l>>4)]
+        auto mfma2Image = [&](const double* Dr, const double* Ds, const double* Lift) {
+            const int MT = kt->mfmaMT, KV = kt->mfmaKV, KF = kt->mfma2KF;
+            std::vector<double> img(static_cast<size_t>(kt->mfma2OpsDoubles), 0.0);
+            const std::vector<double> first = mfmaImage(Dr, Ds, Lift);
+            std::copy(first.begin(), first.begin() + static_cast<size_t>(2) * MT * KV * 64, img.begin());
+            const size_t off = static_cast<size_t>(2) * MT * KV * 64;
+            for (int r = 0; r < MT; ++r)
+                for (int f = 0; f < 3; ++f)
+                    for (int tf = 0; tf < KF; ++tf)
+                        for (int l = 0; l < 64; ++l) {
+                            const int i = 16 * r + (l & 15), n = 4 * tf + (l >> 4);
+                            if (i < Np && n < Nfp)
+                                img[off + ((static_cast<size_t>(r) * 3 + f) * KF + tf) * 64 + l] = Lift[i * NFN + f * Nfp + n];
+                        }
+            return img;
+        };
+        {
+            const std::vector<double> img2 = mfma2Image(d.Dr, d.Ds, d.Lift);
+            s->opsMfma2.alloc(img2.size(), s->bytes);
+            hipCheck(hipMemcpy(s->opsMfma2.p, img2.data(), img2.size() * sizeof(double), hipMemcpyHostToDevice), "mfma2 ops upload");
+        }
         {
             const std::vector<double> img = mfmaImage(d.Dr, d.Ds, d.Lift);
             s->opsMfma.alloc(img.size(), s->bytes);
@@ -733,6 +760,12 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
             // Filter * (Dr, Ds, Lift): the filtered RHS of an affine element is linear in these.
             const std::vector<double> FDr = matmulHost(d.Filter, d.Dr, Np, Np), FDs = matmulHost(d.Filter, d.Ds, Np, Np),
                                       FL = matmulHost(d.Filter, d.Lift, Np, NFN);
+            {
+                const std::vector<double> img2 = mfma2Image(FDr.data(), FDs.data(), FL.data());
+                s->opsMfma2Filtered.alloc(img2.size(), s->bytes);
+                hipCheck(hipMemcpy(s->opsMfma2Filtered.p, img2.data(), img2.size() * sizeof(double), hipMemcpyHostToDevice),
+                         "filtered mfma2 ops upload");
+            }
             {
                 const std::vector<double> img = mfmaImage(FDr.data(), FDs.data(), FL.data());
                 s->opsMfmaFiltered.alloc(img.size(), s->bytes);

@@ -19,6 +19,8 @@ struct KernelTable {
     // matrix-core path (v_mfma_f64_16x16x4_f64), straight-sided elements; needs ldsBytes of dynamic LDS
     int mfmaOpsDoubles, mfmaMT, mfmaKV, mfmaKS;
     hipError_t (*stageMfma)(int mode, const StageParams& p, hipStream_t stream);
+    int mfma2OpsDoubles, mfma2KF; // face-by-face schedule (lift tiles padded per face)
+    hipError_t (*stageMfma2)(int mode, const StageParams& p, hipStream_t stream);
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);

@@ -219,3 +219,219 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
 }
 
 } // namespace bdg_dev
+
+namespace bdg_dev {
+
+// ---------------------------------------------------------------------------------------------
+// Second schedule of the same computation, organised for a 256-register budget (two waves per
+// SIMD, so one wave's loads, shuffles and stores hide under the other's MFMAs):
+//   * the surface term is processed face by face, each face padded to KF = ceil(Nfp/4) k-steps, so
+//     the jump data of only one face is alive while its Lax-Friedrichs speed is reduced;
+//   * the volume term runs in chunks of VC k-steps with the next chunk's state loads in flight;
+//   * the stage update handles one field at a time.
+template <int N>
+struct MfmaOps2 {
+    using E = Elem<N>;
+    static constexpr int MT = (E::Np + 15) / 16;
+    static constexpr int KV = (E::Np + 3) / 4;
+    static constexpr int KF = (E::Nfp + 3) / 4;    // k-steps per face
+    static constexpr int OFF_DR = 0;
+    static constexpr int OFF_DS = MT * KV * 64;
+    static constexpr int OFF_LIFT = 2 * MT * KV * 64; // [r][f][tf][64], lane l = Lift'[16r + (l&15)][f*Nfp + 4tf + (l>>4)]
+    static constexpr int DOUBLES = OFF_LIFT + MT * 3 * KF * 64;
+};
+
+template <int N, int MODE>
+__global__ __launch_bounds__(256, 2) void sw2d_stage_mfma2_kernel(const StageParams p) {
+    using E = Elem<N>;
+    using O = MfmaOps2<N>;
+    constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
+
+    extern __shared__ double sOps[];
+    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const unsigned blk = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const unsigned wave = blk * 4u + (threadIdx.x >> 6), nwaves = nwg * 4u;
+    const unsigned ntiles = (static_cast<unsigned>(p.kend - p.kbegin) + 15u) / 16u;
+    const unsigned perWave = (ntiles + nwaves - 1u) / nwaves;
+    const unsigned tileEnd = min(ntiles, (wave + 1u) * perWave);
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
+    const double* __restrict__ qin = p.qin;
+    const double* __restrict__ ag = p.ageo;
+    const double g = p.g, halfg = 0.5 * p.g;
+    const unsigned kLast = static_cast<unsigned>(p.kend) - 1u;
+
+#pragma unroll 1
+    for (unsigned tile = wave * perWave; tile < tileEnd; ++tile) {
+        const unsigned kTrue = static_cast<unsigned>(p.kbegin) + tile * 16u + j;
+        const bool live = kTrue <= kLast;
+        const unsigned k = live ? kTrue : kLast;
+        const unsigned k8 = k * 8u, k4 = k * 4u;
+
+        mfma_acc_t acc[3][MT];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) acc[c][r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+
+        // ---- volume term in chunks of VC k-steps, next chunk's loads in flight
+        {
+            const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
+                         sy = ld_row(ag + 3 * ld, k8);
+            constexpr int VC = 3, NC = (KV + VC - 1) / VC;
+            double hb[2][VC], hub[2][VC], hvb[2][VC];
+            auto loadChunk = [&](int ch, int buf) {
+#pragma unroll
+                for (int s = 0; s < VC; ++s) {
+                    const int t = ch * VC + s, m = 4 * t + static_cast<int>(q);
+                    hb[buf][s] = 1.0; hub[buf][s] = 0.0; hvb[buf][s] = 0.0;
+                    if (t < KV && m < Np) {
+                        hb[buf][s] = ld_row(qin + m * ld, k8);
+                        hub[buf][s] = ld_row(qin + plane + m * ld, k8);
+                        hvb[buf][s] = ld_row(qin + 2 * plane + m * ld, k8);
+                    }
+                }
+            };
+            loadChunk(0, 0);
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                const int cur = ch & 1;
+                if (ch + 1 < NC) loadChunk(ch + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < VC; ++s) {
+                    const int t = ch * VC + s;
+                    if (t < KV) {
+                        const int m = 4 * t + static_cast<int>(q);
+                        const double h = hb[cur][s], hu = hub[cur][s], hv = hvb[cur][s];
+                        const double r = fast_rcp(h);
+                        const double u = hu * r, v = hv * r;
+                        const double pr = halfg * h * h;
+                        const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
+                        const double w = m < Np ? -1.0 : 0.0; // zero the padded rows of the operand
+                        const double a1 = w * (rx * hu + ry * hv), b1 = w * (sx * hu + sy * hv);
+                        const double a2 = w * (rx * F2 + ry * G2), b2 = w * (sx * F2 + sy * G2);
+                        const double a3 = w * (rx * G2 + ry * G3), b3 = w * (sx * G2 + sy * G3);
+#pragma unroll
+                        for (int r2 = 0; r2 < MT; ++r2) {
+                            const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
+                            const double Ads = sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane];
+                            acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a1, acc[0][r2], 0, 0, 0);
+                            acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a2, acc[1][r2], 0, 0, 0);
+                            acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a3, acc[2][r2], 0, 0, 0);
+                            acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b1, acc[0][r2], 0, 0, 0);
+                            acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b2, acc[1][r2], 0, 0, 0);
+                            acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b3, acc[2][r2], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- surface term, one face at a time (face node n = 4*tf + q of face f)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const double nxf = ld_row(ag + (4 + f) * ld, k8), nyf = ld_row(ag + (7 + f) * ld, k8);
+            const double hfs = 0.5 * ld_row(ag + (10 + f) * ld, k8);
+            double e1[KF], e2[KF], e3[KF], d1[KF], d2[KF], d3[KF];
+            double lam = 0.0;
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const int n = 4 * tf + static_cast<int>(q);
+                e1[tf] = e2[tf] = e3[tf] = d1[tf] = d2[tf] = d3[tf] = 0.0;
+                if (n < Nfp) {
+                    const int jf = f * Nfp + n, m = fmask_rt<N>(f, n);
+                    const int id = ld_row(p.vmapP + jf * ld, k4);
+                    const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
+                                 hvM = ld_row(qin + 2 * plane + m * ld, k8);
+                    const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
+                    const double hq = ld_row(qin, o8);
+                    double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
+                    if (id < 0) { // reflective wall: no normal flow
+                        const double un = huM * nxf + hvM * nyf;
+                        huq = huM - 2 * nxf * un;
+                        hvq = hvM - 2 * nyf * un;
+                    }
+                    const double rM = fast_rcp(hM), rP = fast_rcp(hq);
+                    const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
+                    const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                    const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                    lam = fmax(lam, fmax(spdM, spdP));
+                    const double prM = halfg * hM * hM, prP = halfg * hq * hq;
+                    const double F2M = huM * uM + prM, G2M = huM * vM, G3M = hvM * vM + prM;
+                    const double F2P = huq * uP + prP, G2P = huq * vP, G3P = hvq * vP + prP;
+                    d1[tf] = hM - hq; d2[tf] = huM - huq; d3[tf] = hvM - hvq;
+                    e1[tf] = d2[tf] * nxf + d3[tf] * nyf;
+                    e2[tf] = (F2M - F2P) * nxf + (G2M - G2P) * nyf;
+                    e3[tf] = (G2M - G2P) * nxf + (G3M - G3P) * nyf;
+                }
+            }
+            lam = fmax(lam, __shfl_xor(lam, 16));
+            lam = fmax(lam, __shfl_xor(lam, 32));
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const double s1 = hfs * (e1[tf] - lam * d1[tf]);
+                const double s2 = hfs * (e2[tf] - lam * d2[tf]);
+                const double s3 = hfs * (e3[tf] - lam * d3[tf]);
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    const double Al = sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane];
+                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s1, acc[0][r], 0, 0, 0);
+                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s2, acc[1][r], 0, 0, 0);
+                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s3, acc[2][r], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- stage update / output, one field at a time
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const long long fo = static_cast<long long>(c) * plane;
+                double oldv[MT][4], qv[MT][4];
+                if constexpr (MODE != MODE_RHS) {
+                    const double* __restrict__ base2 = ((MODE == MODE_LSERK) ? p.res : p.qbase) + fo;
+#pragma unroll
+                    for (int r = 0; r < MT; ++r)
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg) {
+                            const int i = 16 * r + static_cast<int>(q) + 4 * reg;
+                            if (i < Np) {
+                                qv[r][reg] = ld_row(qin + fo + i * ld, k8);
+                                oldv[r][reg] = ld_row(base2 + i * ld, k8);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = 16 * r + static_cast<int>(q) + 4 * reg;
+                        if (i < Np) {
+                            const double R = acc[c][r][reg];
+                            if constexpr (MODE == MODE_RHS) {
+                                st_row(p.rhs + fo + i * ld, k8, R);
+                            } else if constexpr (MODE == MODE_LSERK) {
+                                const double n1 = p.ca * oldv[r][reg] + p.cc * R;
+                                st_row(p.res + fo + i * ld, k8, n1);
+                                st_row(p.qout + fo + i * ld, k8, qv[r][reg] + p.cb * n1);
+                            } else {
+                                const double val = p.ca * oldv[r][reg] + p.cb * qv[r][reg] + p.cc * R;
+                                st_row(p.qout + fo + i * ld, k8, c == 0 ? val : sponge_relax(val, p.sponge));
+                            }
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+}
+
+} // namespace bdg_dev

@@ -133,6 +133,26 @@ hipError_t stageMfma(int mode, const StageParams& p, hipStream_t stream) {
 }
 
 template <int MODE>
+hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const size_t ldsBytes = sizeof(double) * MfmaOps2<kN>::DOUBLES;
+    const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
+    const unsigned perCu = static_cast<unsigned>(std::min<size_t>(2, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
+    const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
+    hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t stageMfma2(int mode, const StageParams& p, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchMfma2<MODE_RHS>(p, stream);
+    case MODE_LSERK: return launchMfma2<MODE_LSERK>(p, stream);
+    case MODE_COMBINE: return launchMfma2<MODE_COMBINE>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MODE>
 hipError_t launchVd(const StageParams& p, const VdParams& vp, hipStream_t stream) {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
@@ -167,7 +187,8 @@ int fmaskOf(int f, int n) { return Elem<kN>::fmask(f, n); }
 const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
-                                      MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, VdOps<kN>::DOUBLES, &stageVd, &dt,
+                                      MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
+                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &dt,
                                       &fmaskOf};
     return &table;
 }
