@@ -115,7 +115,8 @@ def run_single(args):
     nodes = dg.TriangleNodesProvisioner(ORDER, mesh)
     ctx = nodes.dgContext()
     K, Np = ctx.numElements, ctx.numLocalPoints
-    solver = sw2d.Sw2dSolver(nodes=nodes, g=G, device=0, flags=sw2d.REORDER if args.reorder else 0)
+    solver = sw2d.Sw2dSolver(nodes=nodes, g=G, device=0, flags=(sw2d.REORDER if args.reorder else 0)
+                             | (sw2d.NODAL_GEOMETRY if args.nodal_geometry else 0))
     h, hu, hv = initial_state(ctx.x, ctx.y)
     solver.setState(h, hu, hv)
     dt, _ = solver.computeDt(CFL)
@@ -270,6 +271,7 @@ def main():
     ap.add_argument("--cells", default=f"{NX}x{NY}", help="box cells NXxNY, 2 triangles each (default 1000x500)")
     ap.add_argument("--shuffle-seed", type=int, default=0, help="Fisher-Yates element shuffle (adversarial ordering)")
     ap.add_argument("--reorder", action="store_true", help="let the solver renumber elements internally (BFS)")
+    ap.add_argument("--nodal-geometry", action="store_true", help="force the per-node-geometry kernels")
     args = ap.parse_args()
     ORDER = args.order
     NX, NY = (int(v) for v in args.cells.lower().split("x"))

@@ -34,7 +34,7 @@ def main():
     into = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--into" else None
     stage = "sw2d_stage"
     summary = {"tag": tag, "kernel": None, "counters": {}, "launches_sampled": {}}
-    for group in ("fetch", "write", "tcc", "sq", "grbm"):
+    for group in ("fetch", "write", "tcc", "sq", "grbm", "mfma"):
         vals, n, extra = counters(os.path.join(out, f"prof_{tag}_{group}"), stage)
         summary["counters"].update(vals)
         summary["launches_sampled"].update(n)
@@ -59,6 +59,13 @@ def main():
             "read_bytes": 2 * c["FETCH_SIZE"] * 1024, "write_bytes": c["WRITE_SIZE"] * 1024,
             "total_bytes": 2 * c["FETCH_SIZE"] * 1024 + c["WRITE_SIZE"] * 1024,
             "note": "reads = 2 x FETCH_SIZE (gfx950 counts 64 B per 128-B request on coalesced streams)"}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+        # MfmaUtil as rocprofv3 defines it: busy cycles summed over SIMDs / (active cycles * 1024 SIMDs);
+        # GRBM_GUI_ACTIVE is the sum over the 8 XCDs (MI355X_MICROARCH.md, DVFS note)
+        summary["mfma_util_percent"] = 100.0 * c["SQ_VALU_MFMA_BUSY_CYCLES"] / ((c["GRBM_GUI_ACTIVE"] / 8.0) * 1024.0)
+        if "SQ_INSTS_VALU_MFMA_MOPS_F64" in c and summary.get("kernel_trace"):
+            flops = c["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512.0
+            summary["mfma_f64_tflops"] = flops / (summary["kernel_trace"]["avg_ns"] * 1e-9) / 1e12
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         summary["l2_hit_rate"] = c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
     print(json.dumps(summary, indent=1))
