@@ -106,6 +106,7 @@ def cpu_baseline(order):
 
 
 def run_single(args):
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 8)))
     import blitzdg_amd.pyblitzdg as dg
     from blitzdg_amd import sw2d
 
@@ -187,14 +188,21 @@ def distributed_line(world, steps, warmup, wall, K, Np, counts, transport):
     }
 
 
+def cap_host_threads(world):
+    """Host-side setup uses OpenMP; with one process per GPU keep the total thread count sane."""
+    cores = os.cpu_count() or 8
+    os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, cores // max(world, 1)))))
+
+
 def run_distributed_native(args):
     """One process per GPU; RCCL driven from the C++ library (no PyTorch in the workers). The
     timed region is bracketed by an all-rank barrier + device synchronisation on both sides and
     the maximum over ranks is taken."""
-    from blitzdg_amd.halo import NativeDistributedSw2d
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cap_host_threads(world)
+    from blitzdg_amd.halo import NativeDistributedSw2d
+
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     d = NativeDistributedSw2d.box(NX, NY, ORDER, rank, world, g=G, device=local_rank)
     try:
