@@ -55,6 +55,12 @@ class Sw2dDesc(Structure):
                 ("coriolis", c_void_p), ("coriolis_const", c_double), ("drag", c_double)]
 
 
+class Sw2dVbDesc(Structure):
+    _fields_ = [("H", c_void_p), ("Hx", c_void_p), ("Hy", c_void_p), ("mapO", c_void_p), ("num_out", c_int),
+                ("drag", c_double), ("coriolis", c_double), ("tide_amplitude", c_double),
+                ("tide_period", c_double), ("tide_ramp", c_double), ("sponge", c_void_p)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -112,6 +118,12 @@ _SIGNATURES = {
     "bdg_sw2d_get_state4": (c_int, [_P, _P, _P, _P, _P]),
     "bdg_sw2d_rhs4": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
     "bdg_sw2d_num_fields": (c_int, [_P]),
+    "bdg_sw2d_enable_variant_b": (c_int, [_P, POINTER(Sw2dVbDesc)]),
+    "bdg_sw2d_set_time": (c_int, [_P, c_double]),
+    "bdg_sw2d_get_time": (c_int, [_P, POINTER(c_double)]),
+    "bdg_sw2d_global_speed": (c_int, [_P, POINTER(c_double)]),
+    "bdg_trinodes_bed_slopes": (c_int, [_P, _P, _P, _P]),
+    "bdg_trinodes_sponge_coeff": (c_int, [_P, _P, c_int, c_double, c_double, _P]),
     "bdg_sw2d_step_lserk4": (c_int, [_P, c_double, c_int]),
     "bdg_sw2d_lserk4_stages": (c_int, [_P, c_double, c_int]),
     "bdg_sw2d_step_rk2": (c_int, [_P, c_double, c_int, c_int]),

@@ -232,6 +232,10 @@ struct DevBuf {
 
 } // namespace
 
+namespace {
+std::vector<double> matmulHost(const double* A, const double* B, int n, int c);
+}
+
 struct bdg_sw2d {
     const bdg_dev::KernelTable* kt = nullptr;
     int N = 0, Np = 0, Nfp = 0, NFN = 0, K = 0, device = 0;
@@ -251,6 +255,14 @@ struct bdg_sw2d {
     bool variantD = false;
     bdg_dev::VdParams vd{};
     DevBuf<double> zxBuf, zyBuf, fcorBuf, opsVd, opsVdFiltered;
+    // variant B (reference src/sw2d/main.cpp:279-484): depth + star states, open boundary, global LF speed, sources
+    bool variantB = false;
+    bdg_dev::VbParams vb{};
+    DevBuf<double> HxBuf, HyBuf, spongeBuf, lamBuf, vbPartials;
+    DevBuf<int> obcBuf;
+    double tideAmp = 0.0, tidePeriod = 1.0, tideRamp = 0.0;
+    double timeNow = 0.0;  // model time of the resident state (tide phase)
+    std::vector<double> hostDr, hostDs, hostLift, hostFilter; // kept for operator images built after creation
     int affineVariant = 0; // 0: unrolled, register-resident state; 2/3: unrolled, streamed state at 2/3 waves
                            // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane; 5: matrix cores (MFMA f64),
                            // whole tile unrolled; 6: matrix cores, face-by-face / chunked schedule at 2 waves per SIMD
@@ -323,7 +335,13 @@ struct bdg_sw2d {
     // One fused pass. The affine path takes the filter through pre-multiplied operators.
     void launchStage(int mode, bool filter, bdg_dev::StageParams& p, const char* what) {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
-        if (variantD) {
+        if (variantB) {
+            // :352  hP = HM + amp cos(om t) 1/2 (tanh(ramp (t - T)) + 1)
+            const double om = 2.0 * M_PI / tidePeriod;
+            vb.tide = tideAmp * std::cos(om * timeNow) * 0.5 * (std::tanh(tideRamp * (timeNow - tidePeriod)) + 1);
+            p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
+            hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, stream), what);
+        } else if (variantD) {
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
             hipCheck(kt->stageVd(mode, p, vd, stream), what);
         } else if (affine && affineVariant == 5) {
@@ -442,6 +460,7 @@ struct bdg_sw2d {
         p.ca = 1.0; p.cb = 0.0; p.cc = dt;
         launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         std::swap(qcur, qalt);
+        timeNow += dt;
     }
 
     // SSP-RK2 (Heun) of the reference's variant-B driver (src/sw2d/main.cpp:211-235), sponge optional:
@@ -454,8 +473,49 @@ struct bdg_sw2d {
         launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
         p.ca = 0.5; p.cb = 0.5; p.cc = 0.5 * dt;
-        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
+        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>"); // same time level (:225)
         std::swap(qcur, qalt);
+        timeNow += dt;
+    }
+
+    // [m][i]{Dr'[i][m], Ds'[i][m], F'[i][m]} + Lift' images (F' = I or Filter) for the rolled
+    // one-field-per-wave kernels (variants B and D)
+    void buildSourceOps() {
+        if (opsVd.p) return;
+        auto image = [&](const double* Dr, const double* Ds, const double* F, const double* Lift) {
+            std::vector<double> img(static_cast<size_t>(3) * Np * Np + static_cast<size_t>(NFN) * Np);
+            for (int m = 0; m < Np; ++m)
+                for (int i = 0; i < Np; ++i) {
+                    const size_t o = 3 * (static_cast<size_t>(m) * Np + i);
+                    img[o] = Dr[i * Np + m];
+                    img[o + 1] = Ds[i * Np + m];
+                    img[o + 2] = F ? F[i * Np + m] : (i == m ? 1.0 : 0.0);
+                }
+            for (int j = 0; j < NFN; ++j)
+                for (int i = 0; i < Np; ++i)
+                    img[static_cast<size_t>(3) * Np * Np + static_cast<size_t>(j) * Np + i] = Lift[i * NFN + j];
+            return img;
+        };
+        const std::vector<double> plain = image(hostDr.data(), hostDs.data(), nullptr, hostLift.data());
+        opsVd.alloc(plain.size(), bytes);
+        hipCheck(hipMemcpy(opsVd.p, plain.data(), plain.size() * sizeof(double), hipMemcpyHostToDevice), "source ops upload");
+        if (!hostFilter.empty()) {
+            const std::vector<double> FDr = matmulHost(hostFilter.data(), hostDr.data(), Np, Np),
+                                      FDs = matmulHost(hostFilter.data(), hostDs.data(), Np, Np),
+                                      FL = matmulHost(hostFilter.data(), hostLift.data(), Np, NFN);
+            const std::vector<double> filt = image(FDr.data(), FDs.data(), hostFilter.data(), FL.data());
+            opsVdFiltered.alloc(filt.size(), bytes);
+            hipCheck(hipMemcpy(opsVdFiltered.p, filt.data(), filt.size() * sizeof(double), hipMemcpyHostToDevice),
+                     "filtered source ops upload");
+        }
+    }
+
+    const double* uploadPlane(const double* host, DevBuf<double>& buf) {
+        if (!host) return nullptr;
+        if (!buf.p) buf.alloc(planeSize(), bytes);
+        hipCheck(hipMemsetAsync(buf.p, 0, buf.n * sizeof(double), stream), "hipMemset");
+        uploadRows(host, buf.p, Np);
+        return buf.p;
     }
 
     // Returns {max |Fscale|*spd, max |eta|}; NaN if any entry is NaN.
@@ -780,32 +840,12 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     }
 
     // ---- variant D: operator image with a third row per (m, i) (identity or Filter) + source tables
+    s->hostDr.assign(d.Dr, d.Dr + static_cast<size_t>(Np) * Np);
+    s->hostDs.assign(d.Ds, d.Ds + static_cast<size_t>(Np) * Np);
+    s->hostLift.assign(d.Lift, d.Lift + static_cast<size_t>(Np) * NFN);
+    if (d.Filter) s->hostFilter.assign(d.Filter, d.Filter + static_cast<size_t>(Np) * Np);
     if (s->variantD) {
-        auto vdImage = [&](const double* Dr, const double* Ds, const double* F, const double* Lift) {
-            std::vector<double> img(static_cast<size_t>(3) * Np * Np + static_cast<size_t>(NFN) * Np);
-            for (int m = 0; m < Np; ++m)
-                for (int i = 0; i < Np; ++i) {
-                    const size_t o = 3 * (static_cast<size_t>(m) * Np + i);
-                    img[o] = Dr[i * Np + m];
-                    img[o + 1] = Ds[i * Np + m];
-                    img[o + 2] = F ? F[i * Np + m] : (i == m ? 1.0 : 0.0);
-                }
-            for (int j = 0; j < NFN; ++j)
-                for (int i = 0; i < Np; ++i)
-                    img[static_cast<size_t>(3) * Np * Np + static_cast<size_t>(j) * Np + i] = Lift[i * NFN + j];
-            return img;
-        };
-        const std::vector<double> plain = vdImage(d.Dr, d.Ds, nullptr, d.Lift);
-        s->opsVd.alloc(plain.size(), s->bytes);
-        hipCheck(hipMemcpy(s->opsVd.p, plain.data(), plain.size() * sizeof(double), hipMemcpyHostToDevice), "vd ops upload");
-        if (d.Filter) {
-            const std::vector<double> FDr = matmulHost(d.Filter, d.Dr, Np, Np), FDs = matmulHost(d.Filter, d.Ds, Np, Np),
-                                      FL = matmulHost(d.Filter, d.Lift, Np, NFN);
-            const std::vector<double> filt = vdImage(FDr.data(), FDs.data(), d.Filter, FL.data());
-            s->opsVdFiltered.alloc(filt.size(), s->bytes);
-            hipCheck(hipMemcpy(s->opsVdFiltered.p, filt.data(), filt.size() * sizeof(double), hipMemcpyHostToDevice),
-                     "filtered vd ops upload");
-        }
+        s->buildSourceOps();
         s->vd.nf = s->nf;
         s->vd.sources = d.sources ? 1 : 0;
         s->vd.fconst = d.coriolis_const;
@@ -932,6 +972,79 @@ int bdg_sw2d_set_bathymetry(bdg_sw2d* s, const double* H) {
         hipCheck(hipMemsetAsync(s->Hbuf.p, 0, s->Hbuf.n * sizeof(double), s->stream), "hipMemset");
         s->uploadRows(H, s->Hbuf.p, s->Np);
         s->hasH = true;
+    });
+}
+
+int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* d) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_enable_variant_b");
+        if (!d || !d->H || !d->Hx || !d->Hy) throw arg_error("bdg_sw2d_enable_variant_b: H, Hx and Hy are required");
+        if (s->nf != 3 || s->variantD)
+            throw arg_error("bdg_sw2d_enable_variant_b: the solver was created with tracer / variant-D sources");
+        if (!s->affine)
+            throw arg_error("bdg_sw2d_enable_variant_b: implemented for straight-sided (affine) geometry only");
+        if (s->numOwned != s->K || s->comm)
+            throw arg_error("bdg_sw2d_enable_variant_b: not available on a partitioned solver (global wave speed)");
+        if (d->num_out < 0 || (d->num_out > 0 && !d->mapO)) throw arg_error("bdg_sw2d_enable_variant_b: bad open-boundary list");
+        if (!(d->tide_period > 0.0) && d->num_out > 0) throw arg_error("bdg_sw2d_enable_variant_b: tide_period must be > 0");
+        const size_t nFaceNodes = static_cast<size_t>(s->NFN) * s->K;
+        for (int i = 0; i < d->num_out; ++i)
+            if (d->mapO[i] < 0 || static_cast<size_t>(d->mapO[i]) >= nFaceNodes)
+                throw arg_error("bdg_sw2d_enable_variant_b: open-boundary node index out of range");
+        s->use();
+        s->buildSourceOps();
+        if (!s->Hbuf.p) s->Hbuf.alloc(s->planeSize(), s->bytes);
+        hipCheck(hipMemsetAsync(s->Hbuf.p, 0, s->Hbuf.n * sizeof(double), s->stream), "hipMemset");
+        // padding lanes are never computed, but give them a positive depth anyway
+        s->uploadRows(d->H, s->Hbuf.p, s->Np);
+        s->hasH = true;
+        s->vb.H = s->Hbuf.p;
+        s->vb.Hx = s->uploadPlane(d->Hx, s->HxBuf);
+        s->vb.Hy = s->uploadPlane(d->Hy, s->HyBuf);
+        s->vb.sponge = s->uploadPlane(d->sponge, s->spongeBuf);
+        // open-boundary face nodes as one bit mask per element, in device slots
+        std::vector<int> mask(static_cast<size_t>(s->ld), 0);
+        for (int i = 0; i < d->num_out; ++i) {
+            const int k = d->mapO[i] / s->NFN, j = d->mapO[i] % s->NFN;
+            mask[s->permHost.empty() ? k : s->permHost[k]] |= 1 << j;
+        }
+        if (!s->obcBuf.p) s->obcBuf.alloc(static_cast<size_t>(s->ld), s->bytes);
+        hipCheck(hipMemcpy(s->obcBuf.p, mask.data(), mask.size() * sizeof(int), hipMemcpyHostToDevice), "open-boundary upload");
+        s->vb.obc = s->obcBuf.p;
+        if (!s->lamBuf.p) s->lamBuf.alloc(1, s->bytes);
+        if (!s->vbPartials.p) s->vbPartials.alloc(static_cast<size_t>((s->K + 255) / 256), s->bytes);
+        s->vb.lam = s->lamBuf.p;
+        s->vb.fcor = d->coriolis;
+        s->vb.cd = d->drag;
+        s->tideAmp = d->tide_amplitude;
+        s->tidePeriod = d->tide_period > 0.0 ? d->tide_period : 1.0;
+        s->tideRamp = d->tide_ramp;
+        s->variantB = true;
+    });
+}
+
+int bdg_sw2d_set_time(bdg_sw2d* s, double t) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_set_time");
+        s->timeNow = t;
+    });
+}
+
+int bdg_sw2d_get_time(const bdg_sw2d* s, double* t) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_get_time");
+        if (!t) throw arg_error("bdg_sw2d_get_time: NULL argument");
+        *t = s->timeNow;
+    });
+}
+
+int bdg_sw2d_global_speed(bdg_sw2d* s, double* lam) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_global_speed");
+        if (!s->variantB || !lam) throw arg_error("bdg_sw2d_global_speed: variant B is not enabled");
+        s->use();
+        hipCheck(hipMemcpyAsync(lam, s->lamBuf.p, sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H copy");
+        hipCheck(hipStreamSynchronize(s->stream), "sync");
     });
 }
 
@@ -1107,6 +1220,7 @@ int bdg_sw2d_time_lserk4_stages(bdg_sw2d* s, double dt, int num_stages, float* m
 int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const int* send_elements, int num_send) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_set_partition");
+        if (s->variantB) throw arg_error("bdg_sw2d_set_partition: not available with variant B (global wave speed)");
         if (!s->permHost.empty())
             throw arg_error("bdg_sw2d_set_partition: the solver renumbered its elements; create it with BDG_SW2D_KEEP_ORDER");
         if (num_interior < 0 || num_interior > num_owned || num_owned > s->K || num_send < 0 ||

@@ -4,6 +4,7 @@
 #pragma once
 #include "sw2d_affine_kernel.hpp"
 #include "sw2d_vd_kernel.hpp"
+#include "sw2d_vb_kernel.hpp"
 #include "sw2d_mfma_kernel.hpp"
 #include "sw2d_kernels.hpp"
 
@@ -24,6 +25,10 @@ struct KernelTable {
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);
+    // variant B (depth, star states, open boundary, global Lax-Friedrichs speed, sources): speed pass over
+    // [kbegin, kend) into partials (one double per 256 elements) and *lam, then the fused stage pass
+    hipError_t (*stageVb)(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam,
+                          hipStream_t stream);
     // per-block partial maxima (2 doubles per block of 256 elements)
     hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
                      double* partials, hipStream_t stream);

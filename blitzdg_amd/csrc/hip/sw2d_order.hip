@@ -169,6 +169,26 @@ hipError_t stageVd(int mode, const StageParams& p, const VdParams& vp, hipStream
     }
 }
 
+template <int MODE>
+hipError_t launchVb(const StageParams& p, const VbParams& vp, double* partials, double* lam, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned nblocks = static_cast<unsigned>((p.kend - p.kbegin + 255) / 256);
+    hipLaunchKernelGGL((sw2d_vb_speed_kernel<kN>), dim3(nblocks), dim3(256), 0, stream, p, vp, partials);
+    hipLaunchKernelGGL((sw2d_vb_speed_reduce_kernel<kN>), dim3(1), dim3(256), 0, stream, partials, static_cast<int>(nblocks), lam);
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
+    hipLaunchKernelGGL((sw2d_stage_vb_kernel<kN, MODE>), dim3(grid), dim3(192), 0, stream, p, vp);
+    return hipGetLastError();
+}
+
+hipError_t stageVb(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchVb<MODE_RHS>(p, vp, partials, lam, stream);
+    case MODE_LSERK: return launchVb<MODE_LSERK>(p, vp, partials, lam, stream);
+    case MODE_COMBINE: return launchVb<MODE_COMBINE>(p, vp, partials, lam, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 hipError_t dt(const double* q, const double* fscale, const double* H, long long ld, int K, double g, double* partials,
               hipStream_t stream) {
     const unsigned grid = static_cast<unsigned>((K + kBlock - 1) / kBlock);
@@ -188,7 +208,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &dt,
+                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &stageVb, &dt,
                                       &fmaskOf};
     return &table;
 }

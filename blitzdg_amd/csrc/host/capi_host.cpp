@@ -6,7 +6,9 @@
 #include "blitzdg/Advec1d.hpp"
 #include "blitzdg/LSERK4.hpp"
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <vector>
 
 using namespace blitzdg;
 
@@ -129,6 +131,72 @@ int bdg_trinodes_build_bchash(bdg_trinodes* nodes, const int* bctype, int n) {
         index_vector_type bc(n);
         std::copy(bctype, bctype + n, bc.begin());
         nodes->prov.buildBCHash(bc);
+    });
+}
+
+// Hx, Hy of the variant-B driver (reference src/sw2d/main.cpp:128-133): physical gradient of H, then the
+// dealiasing filter applied to each component.
+int bdg_trinodes_bed_slopes(const bdg_trinodes* nodes, const double* H, double* Hx, double* Hy) {
+    return guard([&] {
+        if (!nodes || !H || !Hx || !Hy) throw bdg_detail::arg_error("bdg_trinodes_bed_slopes: NULL argument");
+        const auto& p = nodes->prov;
+        const int Np = p.get_NumLocalPoints(), K = p.get_NumElements();
+        const real_matrix_type& Dr = p.get_Dr(), &Ds = p.get_Ds(), &F = p.get_Filter();
+        if (F.rows() != Np) throw bdg_detail::arg_error("bdg_trinodes_bed_slopes: call buildFilter first");
+        const real_matrix_type& rx = p.get_rx(), &sx = p.get_sx(), &ry = p.get_ry(), &sy = p.get_sy();
+#pragma omp parallel for schedule(static)
+        for (int k = 0; k < K; ++k) {
+            std::vector<double> gx(Np), gy(Np);
+            for (int i = 0; i < Np; ++i) {
+                double dr = 0.0, ds = 0.0;
+                for (int m = 0; m < Np; ++m) {
+                    dr += Dr(i, m) * H[static_cast<size_t>(m) * K + k];
+                    ds += Ds(i, m) * H[static_cast<size_t>(m) * K + k];
+                }
+                gx[i] = rx(i, k) * dr + sx(i, k) * ds;
+                gy[i] = ry(i, k) * dr + sy(i, k) * ds;
+            }
+            for (int i = 0; i < Np; ++i) {
+                double ax = 0.0, ay = 0.0;
+                for (int m = 0; m < Np; ++m) {
+                    ax += F(i, m) * gx[m];
+                    ay += F(i, m) * gy[m];
+                }
+                Hx[static_cast<size_t>(i) * K + k] = ax;
+                Hy[static_cast<size_t>(i) * K + k] = ay;
+            }
+        }
+    });
+}
+
+// buildSpongeCoeff (reference src/sw2d/main.cpp:516-556): strength*(1 - d/radius) where d < radius is
+// the distance to the closest open-boundary node, 0 elsewhere.
+int bdg_trinodes_sponge_coeff(const bdg_trinodes* nodes, const int* mapO, int num_out, double strength, double radius,
+                              double* coeff) {
+    return guard([&] {
+        if (!nodes || !coeff || num_out < 0 || (num_out > 0 && !mapO))
+            throw bdg_detail::arg_error("bdg_trinodes_sponge_coeff: bad argument");
+        const auto& p = nodes->prov;
+        const int Np = p.get_NumLocalPoints(), K = p.get_NumElements(), NFN = 3 * p.get_NumFacePoints();
+        const real_matrix_type& x = p.get_xGrid(), &y = p.get_yGrid();
+        const index_vector_type& vmapM = p.get_vmapM();
+        std::vector<double> xo(num_out), yo(num_out);
+        for (int i = 0; i < num_out; ++i) {
+            if (mapO[i] < 0 || mapO[i] >= NFN * K) throw bdg_detail::arg_error("bdg_trinodes_sponge_coeff: node index out of range");
+            const int v = vmapM(mapO[i]);
+            xo[i] = x(v % Np, v / Np);
+            yo[i] = y(v % Np, v / Np);
+        }
+#pragma omp parallel for schedule(static)
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < Np; ++n) {
+                double closest = 1.0e12;
+                for (int i = 0; i < num_out; ++i) {
+                    const double dist = std::hypot(x(n, k) - xo[i], y(n, k) - yo[i]);
+                    if (dist < radius && dist < closest) closest = dist;
+                }
+                coeff[static_cast<size_t>(n) * K + k] = closest < 1.0e12 ? strength * (1.0 - closest / radius) : 0.0;
+            }
     });
 }
 

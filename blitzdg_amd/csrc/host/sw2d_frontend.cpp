@@ -4,9 +4,12 @@
 #include "blitzdg/SW2d.hpp"
 #include "blitzdg/MeshManager.hpp"
 #include "blitzdg_hip.h"
+#include <cmath>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 namespace blitzdg {
 namespace sw2d {
@@ -79,6 +82,158 @@ void releaseDeviceImage(const TriangleNodesProvisioner& nodes) {
     cache().erase(it);
 }
 
+// ---------------------------------------------------------------- variant B (src/sw2d/main.cpp)
+
+namespace {
+
+struct VbEntry {
+    bdg_sw2d* solver = nullptr;
+    real_type g = 0, CD = 0, f = 0;
+    std::vector<real_type> H, Hx, Hy; // what the device image was built from
+};
+std::map<const void*, VbEntry>& vbCache() {
+    static std::map<const void*, VbEntry> c;
+    return c;
+}
+
+bool same(const std::vector<real_type>& kept, const real_matrix_type& m) {
+    const size_t n = static_cast<size_t>(m.rows()) * m.cols();
+    return kept.size() == n && std::memcmp(kept.data(), m.data(), n * sizeof(real_type)) == 0;
+}
+
+const std::vector<index_type>& nodesOf(const index_hashmap& bc, index_type tag) {
+    static const std::vector<index_type> none;
+    const auto it = bc.find(tag);
+    return it == bc.end() ? none : it->second;
+}
+
+bdg_sw2d* variantBSolver(const fields& fds, const physParams& phys, const DGContext2D& dg) {
+    const index_type Np = dg.numLocalPoints(), K = dg.numElements();
+    for (const real_matrix_type* m : {&fds.h, &fds.hu, &fds.hv, &fds.H, &fds.Hx, &fds.Hy}) requireShape(*m, Np, K, "computeRHS");
+    VbEntry& e = vbCache()[dg.vmapP().data()];
+    if (e.solver && (e.g != phys.g)) {
+        bdg_sw2d_destroy(e.solver);
+        e = VbEntry{};
+    }
+    if (!e.solver) {
+        bdg_sw2d_desc d{};
+        d.order = dg.order();
+        d.num_elements = K;
+        d.Dr = dg.Dr().data(); d.Ds = dg.Ds().data(); d.Lift = dg.lift().data();
+        d.Filter = dg.filter().rows() == Np ? dg.filter().data() : nullptr;
+        d.rx = dg.rx().data(); d.sx = dg.sx().data(); d.ry = dg.ry().data(); d.sy = dg.sy().data();
+        d.nx = dg.nx().data(); d.ny = dg.ny().data(); d.Fscale = dg.fscale().data();
+        d.vmapM = dg.vmapM().data(); d.vmapP = dg.vmapP().data();
+        const std::vector<index_type>& mapW = nodesOf(dg.bcmap(), BCTag::Wall);
+        d.mapW = mapW.data(); d.num_wall = static_cast<int>(mapW.size());
+        d.g = phys.g;
+        check(bdg_sw2d_create(&d, &e.solver));
+        e.g = phys.g;
+    }
+    if (!same(e.H, fds.H) || !same(e.Hx, fds.Hx) || !same(e.Hy, fds.Hy) || e.CD != phys.CD || e.f != phys.f) {
+        const std::vector<index_type>& mapO = nodesOf(dg.bcmap(), BCTag::Out);
+        bdg_sw2d_vb_desc v{};
+        v.H = fds.H.data(); v.Hx = fds.Hx.data(); v.Hy = fds.Hy.data();
+        v.mapO = mapO.data(); v.num_out = static_cast<int>(mapO.size());
+        v.drag = phys.CD; v.coriolis = phys.f;
+        v.tide_amplitude = 3.0; v.tide_period = 3600 * 12.42; v.tide_ramp = 0.15 / 3600; // main.cpp:280-282,352
+        check(bdg_sw2d_enable_variant_b(e.solver, &v));
+        const size_t n = static_cast<size_t>(Np) * K;
+        e.H.assign(fds.H.data(), fds.H.data() + n);
+        e.Hx.assign(fds.Hx.data(), fds.Hx.data() + n);
+        e.Hy.assign(fds.Hy.data(), fds.Hy.data() + n);
+        e.CD = phys.CD; e.f = phys.f;
+    }
+    return e.solver;
+}
+
+} // namespace
+
+void computeRHS(fields& fds, const numParams&, const physParams& phys, const DGContext2D& dg, real_type t) {
+    std::lock_guard<std::mutex> lock(cacheMutex());
+    bdg_sw2d* solver = variantBSolver(fds, phys, dg);
+    const index_type Np = dg.numLocalPoints(), K = dg.numElements();
+    for (real_matrix_type* m : {&fds.RHS1, &fds.RHS2, &fds.RHS3})
+        if (m->rows() != Np || m->cols() != K) m->resize(Np, K);
+    check(bdg_sw2d_set_time(solver, t));
+    check(bdg_sw2d_rhs(solver, fds.h.data(), fds.hu.data(), fds.hv.data(), fds.RHS1.data(), fds.RHS2.data(),
+                       fds.RHS3.data(), 0));
+}
+
+double computeTimeStep(fields& fds, const physParams& phys, const numParams& num, const DGContext2D& dg) {
+    std::lock_guard<std::mutex> lock(cacheMutex());
+    bdg_sw2d* solver = variantBSolver(fds, phys, dg);
+    const index_type Np = dg.numLocalPoints(), K = dg.numElements();
+    for (real_matrix_type* m : {&fds.u, &fds.v})
+        if (m->rows() != Np || m->cols() != K) m->resize(Np, K);
+    const size_t n = static_cast<size_t>(Np) * K;
+    for (size_t i = 0; i < n; ++i) {                       // main.cpp:259-260 (side effect the caller may read)
+        fds.u.data()[i] = fds.hu.data()[i] / fds.h.data()[i];
+        fds.v.data()[i] = fds.hv.data()[i] / fds.h.data()[i];
+    }
+    check(bdg_sw2d_set_state(solver, fds.h.data(), fds.hu.data(), fds.hv.data()));
+    // the reference does not look at eta here: report only dt (a NaN state still yields NaN)
+    double dt = 0, em = 0;
+    const int rc = bdg_sw2d_compute_dt(solver, num.CFL, &dt, &em);
+    if (rc != BDG_OK && rc != BDG_ERR_UNSTABLE) check(rc);
+    return dt;
+}
+
+void buildSpongeCoeff(const DGContext2D& dg, real_type spongeStrength, real_type radInfl, real_matrix_type& spongeCoeff) {
+    const index_type Np = dg.numLocalPoints(), K = dg.numElements();
+    if (spongeCoeff.rows() != Np || spongeCoeff.cols() != K) spongeCoeff.resize(Np, K);
+    const std::vector<index_type>& mapO = nodesOf(dg.bcmap(), BCTag::Out);
+    const real_matrix_type& x = dg.x(), &y = dg.y();
+    const index_vector_type& vmapM = dg.vmapM();
+    std::vector<real_type> xo(mapO.size()), yo(mapO.size());
+    for (size_t i = 0; i < mapO.size(); ++i) {
+        const index_type v = vmapM(mapO[i]);
+        xo[i] = x(v % Np, v / Np);
+        yo[i] = y(v % Np, v / Np);
+    }
+    for (index_type k = 0; k < K; ++k)
+        for (index_type n = 0; n < Np; ++n) {
+            real_type closest = 1.0e12;
+            for (size_t i = 0; i < mapO.size(); ++i) {
+                const real_type dist = std::hypot(x(n, k) - xo[i], y(n, k) - yo[i]);
+                if (dist < radInfl && dist < closest) closest = dist;
+            }
+            if (closest < 1.0e12) spongeCoeff(n, k) = spongeStrength * (1.0 - closest / radInfl);
+        }
+}
+
+void computeBedSlopes(const DGContext2D& dg, const real_matrix_type& H, real_matrix_type& Hx, real_matrix_type& Hy) {
+    const index_type Np = dg.numLocalPoints(), K = dg.numElements();
+    requireShape(H, Np, K, "computeBedSlopes");
+    if (dg.filter().rows() != Np) throw std::runtime_error("computeBedSlopes: call buildFilter first");
+    for (real_matrix_type* m : {&Hx, &Hy})
+        if (m->rows() != Np || m->cols() != K) m->resize(Np, K);
+    const real_matrix_type& Dr = dg.Dr(), &Ds = dg.Ds(), &F = dg.filter();
+    std::vector<real_type> gx(Np), gy(Np);
+    for (index_type k = 0; k < K; ++k) {
+        for (index_type i = 0; i < Np; ++i) {
+            real_type dr = 0, ds = 0;
+            for (index_type m = 0; m < Np; ++m) { dr += Dr(i, m) * H(m, k); ds += Ds(i, m) * H(m, k); }
+            gx[i] = dg.rx()(i, k) * dr + dg.sx()(i, k) * ds;
+            gy[i] = dg.ry()(i, k) * dr + dg.sy()(i, k) * ds;
+        }
+        for (index_type i = 0; i < Np; ++i) {
+            real_type ax = 0, ay = 0;
+            for (index_type m = 0; m < Np; ++m) { ax += F(i, m) * gx[m]; ay += F(i, m) * gy[m]; }
+            Hx(i, k) = ax;
+            Hy(i, k) = ay;
+        }
+    }
+}
+
+void releaseDeviceImage(const DGContext2D& dg) {
+    std::lock_guard<std::mutex> lock(cacheMutex());
+    const auto it = vbCache().find(dg.vmapP().data());
+    if (it == vbCache().end()) return;
+    bdg_sw2d_destroy(it->second.solver);
+    vbCache().erase(it);
+}
+
 DeviceSolver::DeviceSolver(const TriangleNodesProvisioner& nodes, real_type g, bool withFilter, int device,
                            unsigned flags)
     : h_{createFrom(nodes, g, withFilter, device, flags)}, Np_{nodes.get_NumLocalPoints()},
@@ -112,6 +267,33 @@ void DeviceSolver::computeRHS(const real_matrix_type& h, const real_matrix_type&
 
 void DeviceSolver::stepLSERK4(real_type dt, index_type n) { check(bdg_sw2d_step_lserk4(h_, dt, n)); }
 void DeviceSolver::stepRK2(real_type dt, index_type n, bool filter) { check(bdg_sw2d_step_rk2(h_, dt, n, filter ? 1 : 0)); }
+
+void DeviceSolver::enableVariantB(const real_matrix_type& H, const real_matrix_type& Hx, const real_matrix_type& Hy,
+                                  const std::vector<index_type>& mapO, real_type CD, real_type f,
+                                  const real_matrix_type* sponge, real_type tideAmplitude, real_type tidePeriod,
+                                  real_type tideRamp) {
+    requireShape(H, Np_, K_, "enableVariantB"); requireShape(Hx, Np_, K_, "enableVariantB"); requireShape(Hy, Np_, K_, "enableVariantB");
+    if (sponge) requireShape(*sponge, Np_, K_, "enableVariantB");
+    bdg_sw2d_vb_desc v{};
+    v.H = H.data(); v.Hx = Hx.data(); v.Hy = Hy.data();
+    v.mapO = mapO.data(); v.num_out = static_cast<int>(mapO.size());
+    v.drag = CD; v.coriolis = f;
+    v.tide_amplitude = tideAmplitude; v.tide_period = tidePeriod; v.tide_ramp = tideRamp;
+    v.sponge = sponge ? sponge->data() : nullptr;
+    check(bdg_sw2d_enable_variant_b(h_, &v));
+}
+
+void DeviceSolver::stepSSPRK2(real_type dt, index_type n, bool filter, real_type spongeCoeff) {
+    check(bdg_sw2d_step_ssprk2(h_, dt, n, filter ? 1 : 0, spongeCoeff));
+}
+
+void DeviceSolver::setTime(real_type t) { check(bdg_sw2d_set_time(h_, t)); }
+
+real_type DeviceSolver::time() const {
+    double t = 0;
+    check(bdg_sw2d_get_time(h_, &t));
+    return t;
+}
 
 real_type DeviceSolver::computeTimeStep(real_type CFL, real_type* etaMax) {
     double dt = 0, em = 0;

@@ -158,6 +158,23 @@ class TriangleNodesProvisioner:
         b = C.as_i32(bcType).reshape(-1)
         check(lib.bdg_trinodes_build_bchash(self._h, C.ptr(b), b.size))
 
+    def bedSlopes(self, H):
+        """(Hx, Hy) as the variant-B driver builds them (reference src/sw2d/main.cpp:128-133)."""
+        _, Np, _, K = self._dims()
+        Hh = C.as_f64(H, (Np, K), "H")
+        Hx, Hy = np.empty((Np, K)), np.empty((Np, K))
+        check(lib.bdg_trinodes_bed_slopes(self._h, C.ptr(Hh), C.ptr(Hx), C.ptr(Hy)))
+        return Hx, Hy
+
+    def buildSpongeCoeff(self, mapO, spongeStrength, radInfl):
+        """reference src/sw2d/main.cpp:516-556 (sw2d::buildSpongeCoeff)"""
+        _, Np, _, K = self._dims()
+        mo = C.as_i32(mapO).reshape(-1)
+        out = np.empty((Np, K))
+        check(lib.bdg_trinodes_sponge_coeff(self._h, C.ptr(mo) if mo.size else None, mo.size, float(spongeStrength),
+                                            float(radInfl), C.ptr(out)))
+        return out
+
     def setCoordinates(self, x, y):
         _, Np, _, K = self._dims()
         xa, ya = C.as_f64(x, (Np, K), "x"), C.as_f64(y, (Np, K), "y")

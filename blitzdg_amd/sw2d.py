@@ -125,6 +125,37 @@ class Sw2dSolver:
         Hh = self._field(H, "H") if H is not None else None
         check(lib.bdg_sw2d_set_bathymetry(self._h, C.ptr(Hh)))
 
+    # ---- variant B: physics of the reference's C++ sw2d driver (src/sw2d/main.cpp:279-484)
+    def enableVariantB(self, H, Hx, Hy, mapO=(), CD=0.0, f=0.0, tideAmplitude=3.0, tidePeriod=3600 * 12.42,
+                       tideRamp=0.15 / 3600, sponge=None):
+        """Depth ``H`` with star states, open-boundary nodes ``mapO`` (BCmap[2]) following the tide, one
+        global Lax-Friedrichs speed, bed-slope (``Hx, Hy``) / drag / Coriolis sources. Afterwards
+        computeRHS and the steppers evaluate variant B at ``self.time``; ``sponge`` is the (Np, K)
+        coefficient field stepSSPRK2 relaxes hu, hv with. Defaults are the reference's constants."""
+        Hh, Hxh, Hyh = self._field(H, "H"), self._field(Hx, "Hx"), self._field(Hy, "Hy")
+        mo = C.as_i32(mapO).reshape(-1)
+        sp = self._field(sponge, "sponge") if sponge is not None else None
+        d = C.Sw2dVbDesc(C.ptr(Hh), C.ptr(Hxh), C.ptr(Hyh), C.ptr(mo) if mo.size else None, mo.size, float(CD),
+                         float(f), float(tideAmplitude), float(tidePeriod), float(tideRamp), C.ptr(sp))
+        check(lib.bdg_sw2d_enable_variant_b(self._h, byref(d)))
+
+    @property
+    def time(self):
+        t = c_double()
+        check(lib.bdg_sw2d_get_time(self._h, byref(t)))
+        return t.value
+
+    @time.setter
+    def time(self, t):
+        check(lib.bdg_sw2d_set_time(self._h, float(t)))
+
+    @property
+    def globalSpeed(self):
+        """Global Lax-Friedrichs speed of the latest variant-B evaluation."""
+        v = c_double()
+        check(lib.bdg_sw2d_global_speed(self._h, byref(v)))
+        return v.value
+
     # ---- RHS (host in, host out)
     def computeRHS(self, h, hu, hv, filter=False):
         h, hu, hv = self._field(h, "h"), self._field(hu, "hu"), self._field(hv, "hv")

@@ -198,6 +198,40 @@ int bdg_sw2d_rhs4(bdg_sw2d* s, const double* h, const double* hu, const double* 
                   double* rhs1, double* rhs2, double* rhs3, double* rhs4, int filter);
 int bdg_sw2d_num_fields(const bdg_sw2d* s);
 
+/* ---- "variant B": the physics of the reference's C++ sw2d driver,
+ * computeRHS(fields, numParams, physParams, DGContext2D, t) -- src/sw2d/main.cpp:279-484:
+ * still-water depth H with star states at the faces, open-boundary nodes (BCmap[2]) driven by
+ *   hP = HM + tide_amplitude cos(2 pi t / tide_period) 1/2 (tanh(tide_ramp (t - tide_period)) + 1),
+ * one global Lax-Friedrichs speed, and the sources RHS2 += g h Hx - CD u|u| + f hv,
+ * RHS3 += g h Hy - CD v|u| - f hu. After this call every RHS / stepping entry point of a 3-field
+ * straight-sided solver evaluates variant B at the solver's model time (bdg_sw2d_set_time; the
+ * steppers advance it by dt per step, both Heun evaluations at the old level as main.cpp:211-236).
+ * sponge: (Np, K) coefficient of hu /= 1 + c hu^2 used by bdg_sw2d_step_ssprk2 instead of the
+ * scalar. Hx, Hy are the caller's (bdg_trinodes_bed_slopes builds them as main.cpp:128-133). */
+typedef struct bdg_sw2d_vb_desc {
+    const double* H;       /* (Np, K)                                    */
+    const double* Hx;      /* (Np, K)                                    */
+    const double* Hy;      /* (Np, K)                                    */
+    const int* mapO;       /* flat face-node indices of open-boundary nodes, or NULL */
+    int num_out;
+    double drag;           /* physParams.CD                              */
+    double coriolis;       /* physParams.f                               */
+    double tide_amplitude; /* reference: 3.0                             */
+    double tide_period;    /* reference: 3600*12.42                      */
+    double tide_ramp;      /* reference: 0.15/3600                       */
+    const double* sponge;  /* (Np, K) or NULL                            */
+} bdg_sw2d_vb_desc;
+int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* desc);
+int bdg_sw2d_set_time(bdg_sw2d* s, double t);
+int bdg_sw2d_get_time(const bdg_sw2d* s, double* t);
+/* The global Lax-Friedrichs speed of the most recent variant-B evaluation. */
+int bdg_sw2d_global_speed(bdg_sw2d* s, double* lam);
+/* Host helpers for the variant-B driver set-up: Hx, Hy = Filter (rx Dr H + sx Ds H, ry Dr H + sy Ds H)
+ * (main.cpp:128-133; buildFilter must have been called), and buildSpongeCoeff (main.cpp:516-556). */
+int bdg_trinodes_bed_slopes(const bdg_trinodes* nodes, const double* H, double* Hx, double* Hy);
+int bdg_trinodes_sponge_coeff(const bdg_trinodes* nodes, const int* mapO, int num_out, double strength,
+                              double radius, double* coeff);
+
 /* Resident time stepping (state stays in HBM). */
 int bdg_sw2d_step_lserk4(bdg_sw2d* s, double dt, int num_steps);          /* 5 fused stages per step */
 int bdg_sw2d_lserk4_stages(bdg_sw2d* s, double dt, int num_stages);       /* stage i = count % 5      */

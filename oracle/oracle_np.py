@@ -52,3 +52,128 @@ def sw2d_rhs4(h, hu, hv, hN, zx, zy, g, f, CD, t):
     out[1] -= g * h * zx
     out[2] -= g * h * zy
     return tuple(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# Variant B: the reference's C++ "sw2d" driver (src/sw2d/main.cpp). PARITY UNPINNED for the parts
+# only that file has (the C++ cannot be built here and holds no known-answer test): global
+# Lax-Friedrichs speed, open-boundary tide, star states. The parts it shares with variants A/D are
+# pinned by running this function with ``global_lf=False`` against the golden RHS fixtures
+# (tests/test_oracle.py).
+
+TIDE_PERIOD = 3600 * 12.42   # main.cpp:280
+TIDE_AMPLITUDE = 3.0         # main.cpp:282
+TIDE_RAMP = 0.15 / 3600      # main.cpp:352
+
+
+def tide_elevation(t, amp=TIDE_AMPLITUDE, period=TIDE_PERIOD, ramp=TIDE_RAMP):
+    """main.cpp:352: amp*cos(om t) * 1/2 (tanh(ramp (t - T)) + 1)"""
+    om = 2.0 * np.pi / period
+    return amp * np.cos(om * t) * 0.5 * (np.tanh(ramp * (t - period)) + 1)
+
+
+def bed_slopes(H, t):
+    """main.cpp:128-133: Hx, Hy = Filter * (rx Dr H + sx Ds H, ry Dr H + sy Ds H)"""
+    Hx = t["rx"] * (t["Dr"] @ H) + t["sx"] * (t["Ds"] @ H)
+    Hy = t["ry"] * (t["Dr"] @ H) + t["sy"] * (t["Ds"] @ H)
+    return t["Filter"] @ Hx, t["Filter"] @ Hy
+
+
+def build_sponge_coeff(t, mapO, strength, radius):
+    """main.cpp:516-556 (buildSpongeCoeff): strength*(1 - d/radius), d = distance to the closest
+    open-boundary node when d < radius, else 0."""
+    x, y = t["x"], t["y"]
+    vM = np.asarray(t["vmapM"])
+    o = vM[np.asarray(mapO, dtype=np.int64)]
+    xo, yo = x.flatten("F")[o], y.flatten("F")[o]
+    out = np.zeros_like(x)
+    if len(o) == 0:
+        return out
+    for k in range(x.shape[1]):
+        for n in range(x.shape[0]):
+            d = np.hypot(x[n, k] - xo, y[n, k] - yo)
+            d = d[d < radius]
+            if d.size:
+                out[n, k] = strength * (1.0 - d.min() / radius)
+    return out
+
+
+def sw2d_rhs_b(h, hu, hv, H, Hx, Hy, g, f, CD, time, t, mapO=(), global_lf=True, tide=None):
+    """main.cpp:279-484. t: tables as for sw2d_rhs4; mapO: open-boundary face nodes (BCmap[2])."""
+    Nfp = t["nx"].shape[0] // 3
+    K = t["rx"].shape[1]
+    vM, vP = np.asarray(t["vmapM"]), np.asarray(t["vmapP"])
+    mapW, mapO = np.asarray(t["mapW"], dtype=np.int64), np.asarray(mapO, dtype=np.int64)
+    col = lambda a: a.flatten("F")  # noqa: E731
+    hC, huC, hvC, HC, nxC, nyC = col(h), col(hu), col(hv), col(H), col(t["nx"]), col(t["ny"])
+    hM, hP = hC[vM], hC[vP]
+    huM, huP = huC[vM], huC[vP]
+    hvM, hvP = hvC[vM], hvC[vP]
+    HM, HP = HC[vM], HC[vP]
+    # walls (:340-345) then open boundary (:348-353); the second overrides the first where both apply
+    un = huM[mapW] * nxC[mapW] + hvM[mapW] * nyC[mapW]
+    hP[mapW] = hM[mapW]
+    huP[mapW] = huM[mapW] - 2 * nxC[mapW] * un
+    hvP[mapW] = hvM[mapW] - 2 * nyC[mapW] * un
+    huP[mapO] = huM[mapO]
+    hvP[mapO] = hvM[mapO]
+    hP[mapO] = HM[mapO] + (tide_elevation(time) if tide is None else tide)
+    # star states (:356-368); hM is overwritten first, so the momentum rescale is hMstar*(huM/hMstar)
+    bM, bP = -HM, -HP
+    mx = np.maximum(bP, bM)
+    hMstar = np.maximum(0.0, hM + bM - mx)
+    hPstar = np.maximum(0.0, hP + bP - mx)
+    hM, hP = hMstar, hPstar
+    with np.errstate(divide="ignore", invalid="ignore"):
+        huM, huP = hMstar * (huM / hM), hPstar * (huP / hP)
+        hvM, hvP = hMstar * (hvM / hM), hPstar * (hvP / hP)
+        dq = (hM - hP, huM - huP, hvM - hvP)
+        F2M, G2M, G3M = (huM * huM) / hM + 0.5 * g * hM * hM, (huM * hvM) / hM, (hvM * hvM) / hM + 0.5 * g * hM * hM
+        F2P, G2P, G3P = (huP * huP) / hP + 0.5 * g * hP * hP, (huP * hvP) / hP, (hvP * hvP) / hP + 0.5 * g * hP * hP
+        uM, vMv, uP, vPv = huM / hM, hvM / hM, huP / hP, hvP / hP
+    FM, GM = (huM, F2M, G2M), (hvM, G2M, G3M)
+    FP, GP = (huP, F2P, G2P), (hvP, G2P, G3P)
+    F2, G2, G3 = (hu * hu) / h + 0.5 * g * h * h, (hu * hv) / h, (hv * hv) / h + 0.5 * g * h * h
+    F, G = (hu, F2, G2), (hv, G2, G3)
+    spd = np.maximum(np.sqrt(uM * uM + vMv * vMv) + np.sqrt(g * hM), np.sqrt(uP * uP + vPv * vPv) + np.sqrt(g * hP))
+    if global_lf:
+        lam = np.full_like(spd, spd.max())                            # :414
+    else:
+        lam = np.repeat(spd.reshape(3 * K, Nfp).max(axis=1), Nfp)     # variants A/D: per-face maximum
+    corr = 0.5 * g * hM * hM - 0.5 * g * hMstar * hMstar              # :420-421, identically zero
+    out = []
+    for c in range(3):
+        extra = 0.0 if c == 0 else corr * (nxC if c == 1 else nyC)
+        dflux = 0.5 * ((FM[c] - FP[c]) * nxC + (GM[c] - GP[c]) * nyC - lam * dq[c] - extra)
+        surf = t["Fscale"] * dflux.reshape((3 * Nfp, K), order="F")
+        r = -(t["rx"] * (t["Dr"] @ F[c]) + t["sx"] * (t["Ds"] @ F[c]))
+        r += -(t["ry"] * (t["Dr"] @ G[c]) + t["sy"] * (t["Ds"] @ G[c]))
+        out.append(r + t["Lift"] @ surf)
+    u, v = hu / h, hv / h
+    out[1] += g * h * Hx                                              # :461-468
+    out[2] += g * h * Hy
+    norm_u = np.sqrt(u * u + v * v)
+    out[1] += -CD * u * norm_u                                        # :473-474
+    out[2] += -CD * v * norm_u
+    out[1] += f * hv                                                  # :477-478
+    out[2] += -f * hu
+    return tuple(out)
+
+
+def step_ssprk2_b(h, hu, hv, H, Hx, Hy, g, f, CD, time, dt, nsteps, t, mapO=(), sponge=None):
+    """main.cpp:211-236: Heun steps with both RHS evaluations at the old time level and the sponge
+    relaxation hu /= 1 + c hu^2 after each update."""
+    sp = np.zeros_like(h) if sponge is None else sponge
+    for _ in range(nsteps):
+        r = sw2d_rhs_b(h, hu, hv, H, Hx, Hy, g, f, CD, time, t, mapO)
+        h1, hu1, hv1 = h + dt * r[0], hu + dt * r[1], hv + dt * r[2]
+        hu1 = hu1 / (1.0 + sp * hu1 * hu1)
+        hv1 = hv1 / (1.0 + sp * hv1 * hv1)
+        r = sw2d_rhs_b(h1, hu1, hv1, H, Hx, Hy, g, f, CD, time, t, mapO)
+        h = 0.5 * (h + h1 + dt * r[0])
+        hu = 0.5 * (hu + hu1 + dt * r[1])
+        hv = 0.5 * (hv + hv1 + dt * r[2])
+        hu = hu / (1.0 + sp * hu * hu)
+        hv = hv / (1.0 + sp * hv * hv)
+        time += dt
+    return h, hu, hv, time

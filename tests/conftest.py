@@ -65,3 +65,32 @@ def tables_from_nodes(nodes):
 def relmax(a, b):
     scale = max(np.abs(b).max(), 1e-300)
     return np.abs(np.asarray(a) - np.asarray(b)).max() / scale
+
+
+def variant_b_setup(order, mesh, seed=3):
+    """A variant-B problem on `mesh` the way the reference's driver sets it up
+    (src/sw2d/main.cpp:60-190): faces on the left edge are re-tagged Out (2) and buildBCHash is
+    called AGAIN, which appends (so those nodes stay in the wall list too); sloping depth H, bed
+    slopes through Filter, sponge field around the open boundary. Returns (nodes, tables, extras)."""
+    import blitzdg_amd.pyblitzdg as dg
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    verts = np.asarray(mesh.vertices).reshape(-1, 3)
+    etov = np.asarray(mesh.elements).reshape(-1, 3)
+    bc = np.asarray(mesh.bcType).reshape(-1, 3).copy()
+    xmin = verts[:, 0].min()
+    for f, (a, b) in enumerate(((0, 1), (1, 2), (2, 0))):
+        left = (np.abs(verts[etov[:, a], 0] - xmin) < 1e-12) & (np.abs(verts[etov[:, b], 0] - xmin) < 1e-12)
+        bc[left & (bc[:, f] == 3), f] = 2
+    nodes.buildBCHash(bc.reshape(-1))
+    t = tables_from_nodes(nodes)
+    ctx = nodes.dgContext()
+    mapO = np.array(ctx.BCmap.get(2, []), dtype=np.int32)
+    x, y = t["x"], t["y"]
+    rng = np.random.default_rng(seed)
+    H = 12.0 + 1.5 * x - 0.8 * y * y + 0.3 * np.sin(3 * x) * np.cos(2 * y)
+    h = H + 0.4 * np.exp(-6 * x * x - 6 * y * y) + 0.05 * rng.standard_normal(x.shape)
+    hu = 0.8 * rng.standard_normal(x.shape)
+    hv = 0.8 * rng.standard_normal(x.shape)
+    extras = dict(mapO=mapO, H=H, h=h, hu=hu, hv=hv, CD=2.5e-3, f=1.0070e-4, time=0.37 * 3600 * 12.42)
+    return nodes, t, extras

@@ -178,3 +178,73 @@ def test_variant_d_reduces_to_variant_a():
     scale = max(np.abs(x).max() for x in r3)
     assert max(np.abs(a - b).max() for a, b in zip(r4[:3], r3)) / scale < 1e-13
     assert np.all(r4[3] == 0)
+
+
+# ---- variant B (src/sw2d/main.cpp): restatement in oracle/oracle_np.py
+
+@pytest.mark.parametrize("case", ["coarse_box_N3", "coarse_box_N6", "box6x5_shuffled_N4"])
+def test_variant_b_oracle_with_local_speed_reproduces_the_reference_fixture(case):
+    """Flat bottom, no open boundary, no sources, per-face instead of global Lax-Friedrichs speed:
+    variant B is then variant A, and must reproduce the reference's own RHS output (the parts of
+    main.cpp:279-484 shared with the Python RHS are pinned this way; the rest is unpinned)."""
+    from oracle.oracle_np import sw2d_rhs_b
+    d = load_case(case)
+    z = np.zeros_like(d["h"])
+    r = sw2d_rhs_b(d["h"], d["hu"], d["hv"], 10.0 + z, z, z, float(d["g"]), 0.0, 0.0, 0.0, d, global_lf=False)
+    scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
+    for i in range(3):
+        assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < 1e-14
+
+
+def test_variant_b_sources_agree_with_variant_d_fixture():
+    """Bed slope and Coriolis of variant B (RHS2 += g h Hx + f hv, RHS3 += g h Hy - f hu) are variant
+    D's with zx = -Hx, zy = -Hy (drag differs by D's sign quirk, so CD = 0 here); the tracer is ignored."""
+    import os
+
+    from conftest import GOLDEN
+    from oracle.oracle_np import sw2d_rhs4, sw2d_rhs_b
+    d = np.load(os.path.join(GOLDEN, "sw2d_rhs4_coarse_box_N4.npz"))
+    g = float(d["g"])
+    r4 = sw2d_rhs4(d["h"], d["hu"], d["hv"], d["hN"], d["zx"], d["zy"], g, d["f"], 0.0, d)
+    rb = sw2d_rhs_b(d["h"], d["hu"], d["hv"], 10.0 + 0 * d["h"], -d["zx"], -d["zy"], g, d["f"], 0.0, 0.0, d,
+                    global_lf=False)
+    scale = max(np.abs(x).max() for x in r4[:3])
+    assert max(np.abs(a - b).max() for a, b in zip(rb, r4[:3])) / scale < 1e-14
+
+
+def test_variant_b_global_speed_star_states_and_tide(coarse_mesh):
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    nodes, t, e = variant_b_setup(3, coarse_mesh)
+    Hx, Hy = onp.bed_slopes(e["H"], t)
+    assert len(e["mapO"]) > 0 and set(e["mapO"]) <= set(t["mapW"])  # buildBCHash appended (SURVEY a10)
+    args = (e["h"], e["hu"], e["hv"], e["H"], Hx, Hy, 9.81, e["f"], e["CD"])
+    r_glob = onp.sw2d_rhs_b(*args, e["time"], t, e["mapO"])
+    r_loc = onp.sw2d_rhs_b(*args, e["time"], t, e["mapO"], global_lf=False)
+    assert max(np.abs(a - b).max() for a, b in zip(r_glob, r_loc)) > 1e-3        # the global speed matters
+    r_wall = onp.sw2d_rhs_b(*args, e["time"], t, ())
+    assert max(np.abs(a - b).max() for a, b in zip(r_glob, r_wall)) > 1e-3       # and so does the open boundary
+    r_t2 = onp.sw2d_rhs_b(*args, e["time"] + 3600.0, t, e["mapO"])
+    assert np.abs(r_glob[0] - r_t2[0]).max() > 1e-4                               # tide phase enters
+    # tide formula (main.cpp:352) at a quarter period is ~0 and ramps in with tanh
+    T = onp.TIDE_PERIOD
+    assert abs(onp.tide_elevation(0.25 * T)) < 1e-12
+    assert abs(onp.tide_elevation(50 * T) - 3.0) < 1e-9
+    # lake at rest over a plane bed: continuous H => star states are the traces themselves, and the
+    # pressure gradient (H^2 is quadratic: differentiated exactly) balances the bed-slope source
+    Hl = 12.0 + 1.5 * t["x"] - 0.8 * t["y"]
+    rest = onp.sw2d_rhs_b(Hl, 0 * Hl, 0 * Hl, Hl, *onp.bed_slopes(Hl, t), 9.81, 0.0, 0.0, 0.0, t, ())
+    assert max(np.abs(x).max() for x in rest) < 1e-10
+
+
+def test_variant_b_host_helpers_match_the_restatement(coarse_mesh):
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    nodes, t, e = variant_b_setup(4, coarse_mesh)
+    Hx, Hy = nodes.bedSlopes(e["H"])
+    rx, ry = onp.bed_slopes(e["H"], t)
+    assert relmax(Hx, rx) < 1e-13 and relmax(Hy, ry) < 1e-13
+    sp = nodes.buildSpongeCoeff(e["mapO"], 10.0, 0.6)
+    ref = onp.build_sponge_coeff(t, e["mapO"], 10.0, 0.6)
+    assert np.array_equal(sp, ref) and sp.max() == 10.0 and (sp == 0).any()
+    assert np.all(nodes.buildSpongeCoeff([], 10.0, 0.6) == 0)

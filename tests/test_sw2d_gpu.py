@@ -471,3 +471,147 @@ def test_ssprk2_with_sponge_vs_oracle(order, flags):
         for a, b in zip(s.getState(), ref):
             assert relmax(a, b) < STATE_TOL
     assert np.abs(ref[1] - o.step_ssprk2(h, hu, hv, dt, 4, filter=True, sponge=0.0)[1]).max() > 1e-6
+
+
+# ---- variant B: the C++ sw2d driver's physics (src/sw2d/main.cpp:279-484) against oracle/oracle_np.py
+
+def _variant_b_solver(nodes, e, Hx, Hy, sponge=None, flags=0):
+    s = sw2d.Sw2dSolver(nodes=nodes, flags=flags)
+    s.enableVariantB(e["H"], Hx, Hy, mapO=e["mapO"], CD=e["CD"], f=e["f"], sponge=sponge)
+    s.time = e["time"]
+    return s
+
+
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_variant_b_rhs_vs_oracle(order, coarse_mesh):
+    """computeRHS(fields, num, phys, dg, t): star states over a non-flat bed, open boundary on the left
+    edge (nodes that are ALSO still in the wall list, as after the reference's second buildBCHash),
+    global Lax-Friedrichs speed, bed slope + drag + Coriolis; plain and filtered."""
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    nodes, t, e = variant_b_setup(order, coarse_mesh)
+    Hx, Hy = nodes.bedSlopes(e["H"])
+    s = _variant_b_solver(nodes, e, Hx, Hy)
+    ref = onp.sw2d_rhs_b(e["h"], e["hu"], e["hv"], e["H"], Hx, Hy, 9.81, e["f"], e["CD"], e["time"], t, e["mapO"])
+    scale = max(np.abs(x).max() for x in ref)
+    r = s.computeRHS(e["h"], e["hu"], e["hv"])
+    assert max(np.abs(a - b).max() for a, b in zip(r, ref)) / scale < RHS_TOL
+    # the speed pass: same maximum as the restatement's (contraction-free arithmetic; Newton reciprocal)
+    col = lambda a: a.flatten("F")  # noqa: E731
+    assert s.globalSpeed > np.sqrt(9.81 * e["h"].min())
+    rf = s.computeRHS(e["h"], e["hu"], e["hv"], filter=True)
+    assert max(np.abs(a - t["Filter"] @ b).max() for a, b in zip(rf, ref)) / scale < RHS_TOL
+    # a different tide phase changes the answer, and matches again
+    s.time = e["time"] + 5000.0
+    ref2 = onp.sw2d_rhs_b(e["h"], e["hu"], e["hv"], e["H"], Hx, Hy, 9.81, e["f"], e["CD"], e["time"] + 5000.0, t,
+                          e["mapO"])
+    r2 = s.computeRHS(e["h"], e["hu"], e["hv"])
+    assert np.abs(ref2[0] - ref[0]).max() > 1e-6
+    assert max(np.abs(a - b).max() for a, b in zip(r2, ref2)) / scale < RHS_TOL
+    del col
+
+
+@pytest.mark.parametrize("order,shuffle", [(2, 0), (4, 11)])
+def test_variant_b_ssprk2_driver_loop_vs_oracle(order, shuffle):
+    """The driver's loop body (main.cpp:211-236): Heun with both evaluations at the old time level,
+    sponge FIELD relaxation after each update, time advanced by dt; on a shuffled (renumbered) mesh too."""
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    m = dg.MeshManager()
+    m.buildBoxMesh(8, 6, shuffleSeed=shuffle)
+    nodes, t, e = variant_b_setup(order, m)
+    Hx, Hy = nodes.bedSlopes(e["H"])
+    sponge = nodes.buildSpongeCoeff(e["mapO"], 2.0, 0.7)
+    s = _variant_b_solver(nodes, e, Hx, Hy, sponge=sponge, flags=sw2d.REORDER if shuffle else 0)
+    s.setState(e["h"], e["hu"], e["hv"])
+    dt, _ = s.computeDt(0.25)
+    s.stepSSPRK2(dt, 5)
+    ref = onp.step_ssprk2_b(e["h"], e["hu"], e["hv"], e["H"], Hx, Hy, 9.81, e["f"], e["CD"], e["time"], dt, 5, t,
+                            e["mapO"], sponge)
+    assert abs(s.time - ref[3]) < 1e-9 * ref[3]
+    for a, b in zip(s.getState(), ref[:3]):
+        assert relmax(a, b) < STATE_TOL
+    plain = onp.step_ssprk2_b(e["h"], e["hu"], e["hv"], e["H"], Hx, Hy, 9.81, e["f"], e["CD"], e["time"], dt, 5, t,
+                              e["mapO"], None)
+    assert np.abs(plain[1] - ref[1]).max() > 1e-5  # the sponge field did something
+
+
+def test_variant_b_medium_mesh_properties():
+    """200 000 triangles, N=4: lake at rest over a plane bed stays at rest (well-balanced star states +
+    bed-slope source), and the global speed equals the restatement's maximum."""
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    m = dg.MeshManager()
+    m.buildBoxMesh(400, 250)
+    nodes, t, e = variant_b_setup(4, m)
+    Hl = 12.0 + 1.5 * t["x"] - 0.8 * t["y"]
+    Hx, Hy = nodes.bedSlopes(Hl)
+    s = sw2d.Sw2dSolver(nodes=nodes)
+    s.enableVariantB(Hl, Hx, Hy, CD=e["CD"], f=e["f"])
+    r = s.computeRHS(Hl, 0 * Hl, 0 * Hl)
+    assert max(np.abs(x).max() for x in r) < 1e-7
+    assert abs(s.globalSpeed - np.sqrt(9.81 * Hl.max())) < 1e-12 * s.globalSpeed
+    # moving state with an open boundary: against the restatement (vectorised NumPy, seconds)
+    Hx, Hy = nodes.bedSlopes(e["H"])
+    s2 = _variant_b_solver(nodes, e, Hx, Hy)
+    ref = onp.sw2d_rhs_b(e["h"], e["hu"], e["hv"], e["H"], Hx, Hy, 9.81, e["f"], e["CD"], e["time"], t, e["mapO"])
+    r2 = s2.computeRHS(e["h"], e["hu"], e["hv"])
+    scale = max(np.abs(x).max() for x in ref)
+    assert max(np.abs(a - b).max() for a, b in zip(r2, ref)) / scale < RHS_TOL
+
+
+def test_variant_b_error_paths(coarse_mesh):
+    from conftest import variant_b_setup
+    nodes, t, e = variant_b_setup(3, coarse_mesh)
+    Hx, Hy = nodes.bedSlopes(e["H"])
+    s = sw2d.Sw2dSolver(nodes=nodes, flags=sw2d.NODAL_GEOMETRY)
+    with pytest.raises(BdgError, match="affine"):
+        s.enableVariantB(e["H"], Hx, Hy)
+    s = sw2d.Sw2dSolver(nodes=nodes)
+    with pytest.raises(BdgError, match="variant B is not enabled"):
+        s.globalSpeed
+    with pytest.raises(BdgError, match="out of range"):
+        s.enableVariantB(e["H"], Hx, Hy, mapO=[10 ** 6])
+    tb = {**t, "order": 3}
+    s4 = sw2d.Sw2dSolver(tables=tb, fields=4)
+    with pytest.raises(BdgError, match="tracer"):
+        s4.enableVariantB(e["H"], Hx, Hy)
+
+
+@pytest.mark.parametrize("mode", ["resident", "dropin"])
+def test_cpp_driver_sw2d_tidal_matches_oracle_replay(mode, coarse_mesh):
+    """bin/sw2d is the reference's src/sw2d/main.cpp written against include/blitzdg: variant-B physics,
+    SSP-RK2 + sponge, adaptive dt. Both its device-resident loop and the loop built on the drop-in
+    sw2d::computeRHS(fields, num, phys, dg, t) must land on the oracle replay's state after 12 steps."""
+    import os
+    import re
+    import subprocess
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bin", "sw2d")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    order, steps = 2, 12
+    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), str(order), str(steps), mode],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    m = re.search(r"done: mode=(\w+), steps=(\d+), t=([-+.\deE]+), eta_max=([-+.\deE]+), \|hu\|max=([-+.\deE]+), "
+                  r"\|hv\|max=([-+.\deE]+)", out.stdout)
+    assert m and m.group(1) == mode and int(m.group(2)) == steps, out.stdout
+    t_end, eta_max, humax, hvmax = (float(m.group(i)) for i in (3, 4, 5, 6))
+
+    nodes, t, e = variant_b_setup(order, coarse_mesh)
+    x, y = t["x"], t["y"]
+    H = np.maximum(150.0, 200.0 + 40.0 * x - 25.0 * y * y)
+    Hx, Hy = onp.bed_slopes(H, t)
+    sponge = onp.build_sponge_coeff(t, e["mapO"], 1.0e-3, 0.5)
+    o = oracle_from(t)
+    q, tt = (H.copy(), np.zeros_like(H), np.zeros_like(H)), 0.0
+    for _ in range(steps):
+        dt = o.dt(*q, 0.25, order)
+        *q, tt = onp.step_ssprk2_b(*q, H, Hx, Hy, 9.81, 1.0070e-4, 2.5e-3, tt, dt, 1, t, e["mapO"], sponge)
+    assert abs(t_end - tt) / tt < 1e-10
+    assert np.abs(q[1]).max() > 1e-4          # the tide has set the water moving
+    assert abs(eta_max - np.abs(q[0] - H).max()) / np.abs(q[0] - H).max() < 1e-8
+    assert abs(humax - np.abs(q[1]).max()) / np.abs(q[1]).max() < 1e-8
+    assert abs(hvmax - np.abs(q[2]).max()) / np.abs(q[2]).max() < 1e-8
