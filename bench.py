@@ -222,6 +222,35 @@ def run_distributed_native(args):
         d.close()
 
 
+def run_rehearsal(args):
+    """Schedule rehearsal on ONE GPU: rank 0's share of a --rehearse-world split with loop-back
+    exchanges of the real message sizes. Prints the per-stage time of the overlapped pipeline; the
+    state is not physical (ghosts are this rank's own elements), so no throughput is claimed."""
+    cap_host_threads(1)
+    from blitzdg_amd.halo import NativeDistributedSw2d
+    world = args.rehearse_world
+    out = []
+    ranks = os.environ.get("BDG_REHEARSE_RANKS")
+    for r in ([int(v) for v in ranks.split(",")] if ranks else sorted({0, world // 2, world - 1})):
+        d = NativeDistributedSw2d.box(NX, NY, ORDER, r, world, g=G, device=0, loopback=True)
+        try:
+            d.set_initial_state(initial_state)
+            dt = 0.25 * d.compute_dt(CFL)
+            d.lserk4_stages(dt, args.warmup)
+            d.barrier()
+            t0 = time.perf_counter()
+            d.lserk4_stages(dt, args.steps)
+            issued = time.perf_counter() - t0
+            d.barrier()
+            wall = time.perf_counter() - t0
+            out.append({"rank": r, "ms_per_stage": wall / args.steps * 1e3,
+                        "host_issue_ms_per_stage": issued / args.steps * 1e3, **d.halo_counts()})
+        finally:
+            d.close()
+    print(json.dumps({"rehearsal": True, "world": world, "order": ORDER, "cells": [NX, NY], "steps": args.steps,
+                      "ranks": out}), flush=True)
+
+
 def run_distributed_torch(args):
     import torch
     import torch.distributed as dist
@@ -280,11 +309,15 @@ def main():
     ap.add_argument("--shuffle-seed", type=int, default=0, help="Fisher-Yates element shuffle (adversarial ordering)")
     ap.add_argument("--reorder", action="store_true", help="let the solver renumber elements internally (BFS)")
     ap.add_argument("--nodal-geometry", action="store_true", help="force the per-node-geometry kernels")
+    ap.add_argument("--rehearse-world", type=int, default=0,
+                    help="one-GPU schedule rehearsal of an N-way split (loop-back exchanges; timing only)")
     args = ap.parse_args()
     ORDER = args.order
     NX, NY = (int(v) for v in args.cells.lower().split("x"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or os.environ.get("BDG_BENCH_FORCE_DISTRIBUTED") == "1":
+    if args.rehearse_world > 1:
+        run_rehearsal(args)
+    elif args.gpus > 1 or world > 1 or os.environ.get("BDG_BENCH_FORCE_DISTRIBUTED") == "1":
         run_distributed(args)
     else:
         run_single(args)

@@ -139,6 +139,8 @@ _SIGNATURES = {
     "bdg_comm_unique_id": (c_int, [_P, c_int]),
     "bdg_sw2d_comm_init": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int]),
     "bdg_sw2d_lserk4_stages_exchanged": (c_int, [_P, c_double, c_int]),
+    "bdg_sw2d_local_peers": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int]),
+    "bdg_sw2d_group_lserk4_stages": (c_int, [POINTER(_P), c_int, c_double, c_int]),
     "bdg_sw2d_compute_dt_global": (c_int, [_P, c_double, POINTER(c_double), POINTER(c_double)]),
     "bdg_sw2d_allreduce_max": (c_int, [_P, c_double, POINTER(c_double)]),
     "bdg_sw2d_barrier": (c_int, [_P]),

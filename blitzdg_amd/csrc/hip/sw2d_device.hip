@@ -274,7 +274,9 @@ struct bdg_sw2d {
     ncclComm_t comm = nullptr;
     int commRank = 0, commWorld = 1;
     hipStream_t commStream = nullptr;
-    hipEvent_t evPacked = nullptr, evExchanged = nullptr;
+    hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr};
+    hipEvent_t evPacked[2] = {nullptr, nullptr}, evCopied[2] = {nullptr, nullptr}; // in-process group transport
+    bool localGroup = false;
     DevBuf<double> sendBuf, recvBuf, scalarBuf;
     double* fscaleNodal = nullptr; // (NFN, ld) per-node Fscale plane (time-step reduction)
     double* qcur = nullptr;  // current state
@@ -284,8 +286,8 @@ struct bdg_sw2d {
 
     ~bdg_sw2d() {
         if (comm) (void)rccl().CommDestroy(comm);
-        if (evPacked) (void)hipEventDestroy(evPacked);
-        if (evExchanged) (void)hipEventDestroy(evExchanged);
+        for (hipEvent_t e : {evA[0], evA[1], evB[0], evB[1], evPacked[0], evPacked[1], evCopied[0], evCopied[1]})
+            if (e) (void)hipEventDestroy(e);
         if (commStream) (void)hipStreamDestroy(commStream);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -333,30 +335,40 @@ struct bdg_sw2d {
     }
 
     // One fused pass. The affine path takes the filter through pre-multiplied operators.
-    void launchStage(int mode, bool filter, bdg_dev::StageParams& p, const char* what) {
+    // `on`: stream to launch on (default: the compute stream).
+    void launchStage(int mode, bool filter, bdg_dev::StageParams& p, const char* what, hipStream_t on = nullptr) {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
+        hipStream_t st = on ? on : stream;
+        // Small launches (a rank's share of a many-way split, its partition-boundary strip) are bound by
+        // the latency of one wavefront, not by HBM: the matrix-core kernel gives each wave 16 elements
+        // instead of 64 (measured at N=4: 750 elements 7 us vs 19 us; 125 k elements 48 us vs 56 us;
+        // 250 k elements 136 us vs 109 us -- DESIGN.md section 4).
+        int variant = affineVariant;
+        if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < kSmallLaunch) variant = 5;
         if (variantB) {
             // :352  hP = HM + amp cos(om t) 1/2 (tanh(ramp (t - T)) + 1)
             const double om = 2.0 * M_PI / tidePeriod;
             vb.tide = tideAmp * std::cos(om * timeNow) * 0.5 * (std::tanh(tideRamp * (timeNow - tidePeriod)) + 1);
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
-            hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, stream), what);
+            hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, st), what);
         } else if (variantD) {
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
-            hipCheck(kt->stageVd(mode, p, vd, stream), what);
-        } else if (affine && affineVariant == 5) {
+            hipCheck(kt->stageVd(mode, p, vd, st), what);
+        } else if (affine && variant == 5) {
             p.opsAffine = filter ? opsMfmaFiltered.p : opsMfma.p;
-            hipCheck(kt->stageMfma(mode, p, stream), what);
-        } else if (affine && affineVariant == 6) {
+            hipCheck(kt->stageMfma(mode, p, st), what);
+        } else if (affine && variant == 6) {
             p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
-            hipCheck(kt->stageMfma2(mode, p, stream), what);
+            hipCheck(kt->stageMfma2(mode, p, st), what);
         } else if (affine) {
             p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
-            hipCheck(kt->stageAffine(mode, affineVariant, p, stream), what);
+            hipCheck(kt->stageAffine(mode, variant, p, st), what);
         } else {
-            hipCheck(kt->stage(mode, filter, p, stream), what);
+            hipCheck(kt->stage(mode, filter, p, st), what);
         }
     }
+    static constexpr int kSmallLaunch = 160000; // elements
+    bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
 
     void launchRhs(const double* qin, double* out, bool filter) {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
@@ -368,7 +380,7 @@ struct bdg_sw2d {
 
     // part: 0 = interior elements only (no ghost dependency; state not advanced),
     //       1 = partition-boundary elements, then advance; 2 = all owned elements, then advance.
-    void launchLserkStage(int part = 2) {
+    void launchLserkStage(int part = 2, hipStream_t on = nullptr, bool advance = true) {
         const int s = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
         bdg_dev::StageParams p = baseParams();
         if (part == 0) p.kend = numInterior;
@@ -379,62 +391,82 @@ struct bdg_sw2d {
         p.ca = blitzdg::LSERK4::rk4a[s];
         p.cb = blitzdg::LSERK4::rk4b[s];
         p.cc = dtStage;
-        launchStage(bdg_dev::MODE_LSERK, false, p, "sw2d stage kernel <LSERK>");
-        if (part == 0) return;
+        launchStage(bdg_dev::MODE_LSERK, false, p, "sw2d stage kernel <LSERK>", on);
+        if (part == 0 || !advance) return;
         std::swap(qcur, qalt);
         ++stageCount;
     }
     double dtStage = 0.0;
 
-    void launchPack(double* buf) {
+    void launchPack(double* buf, hipStream_t on = nullptr) {
         if (numSend == 0) return;
         const int rows = nf * Np;
         const long long n = static_cast<long long>(numSend) * rows;
-        hipLaunchKernelGGL(bdg_dev::halo_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream,
-                           qcur, buf, sendSlots.p, numSend, rows, ld);
+        hipLaunchKernelGGL(bdg_dev::halo_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
+                           on ? on : stream, qcur, buf, sendSlots.p, numSend, rows, ld);
         hipCheck(hipGetLastError(), "halo_pack_kernel");
     }
-    void launchUnpack(const double* buf) {
+    void launchUnpack(const double* buf, hipStream_t on = nullptr) {
         const int ghosts = K - numOwned;
         if (ghosts == 0) return;
         const int rows = nf * Np;
         const long long n = static_cast<long long>(ghosts) * rows;
         hipLaunchKernelGGL(bdg_dev::halo_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
-                           stream, qcur, buf, numOwned, ghosts, rows, ld);
+                           on ? on : stream, qcur, buf, numOwned, ghosts, rows, ld);
         hipCheck(hipGetLastError(), "halo_unpack_kernel");
     }
 
-    // One LSERK4 stage of a partitioned run, all on the device:
-    //   compute stream: pack -> [interior elements] ............ wait -> unpack -> [boundary elements]
-    //   comm stream:      wait(pack) -> grouped ncclSend/ncclRecv with every neighbour -> signal
-    // The interior launch hides the exchange; buffers are reused safely because each stage's
-    // pack is ordered after the previous stage's exchange completed on the compute stream.
-    void launchLserkStageExchanged() {
+    // LSERK4 stages of a partitioned run, all on the device, as two concurrent chains:
+    //   compute stream  A:  wait B(s-1) -> [interior elements of stage s] -> signal A(s)
+    //   exchange stream B:  pack(s) -> grouped ncclSend/ncclRecv with every neighbour -> unpack(s)
+    //                       -> wait A(s-1) -> [partition-boundary elements of stage s] -> signal B(s)
+    // The only true dependency loop is boundary -> transfer -> boundary on chain B; the interior
+    // elements (99 % of the work) run beside it and only meet it one stage later:
+    //   interior(s) reads boundary elements' state of stage s-1 and overwrites the buffer boundary(s-1)
+    //   read, hence waits for B(s-1); boundary(s) reads interior neighbours' state of stage s-1 and
+    //   overwrites slots interior(s-1) read, hence waits for A(s-1). Within B, stream order protects
+    //   the send / receive buffers and the ghost slots. Events alternate by stage parity so that a
+    //   wait issued for stage s-1 is not re-armed by the record of stage s.
+    void launchLserkStagesExchanged(double dt, int numStages) {
         if (!comm) throw arg_error("no communicator: call bdg_sw2d_comm_init first");
+        if (numStages <= 0) return;
         const int rows = nf * Np;
-        launchPack(sendBuf.p);
-        hipCheck(hipEventRecord(evPacked, stream), "hipEventRecord");
-        hipCheck(hipStreamWaitEvent(commStream, evPacked, 0), "hipStreamWaitEvent");
-        if (!peers.empty()) {
-            RcclApi& nc = rccl();
-            ncclCheck(nc.GroupStart(), "ncclGroupStart");
-            for (const Peer& pr : peers) {
-                if (pr.recvCount > 0)
-                    ncclCheck(nc.Recv(recvBuf.p + static_cast<size_t>(pr.recvStart) * rows,
-                                      static_cast<size_t>(pr.recvCount) * rows, ncclDouble, pr.rank, comm, commStream),
-                              "ncclRecv");
-                if (pr.sendCount > 0)
-                    ncclCheck(nc.Send(sendBuf.p + static_cast<size_t>(pr.sendStart) * rows,
-                                      static_cast<size_t>(pr.sendCount) * rows, ncclDouble, pr.rank, comm, commStream),
-                              "ncclSend");
+        dtStage = dt;
+        // chain B starts after everything already queued on A (state upload, earlier steps)
+        hipCheck(hipEventRecord(evA[1], stream), "hipEventRecord");
+        hipCheck(hipStreamWaitEvent(commStream, evA[1], 0), "hipStreamWaitEvent");
+        bool haveA = false, haveB = false;
+        for (int i = 0; i < numStages; ++i) {
+            const int cur = i & 1, prev = cur ^ 1;
+            // ---- chain A
+            if (haveB) hipCheck(hipStreamWaitEvent(stream, evB[prev], 0), "hipStreamWaitEvent");
+            launchLserkStage(0);
+            hipCheck(hipEventRecord(evA[cur], stream), "hipEventRecord");
+            // ---- chain B
+            launchPack(sendBuf.p, commStream);
+            if (!peers.empty()) {
+                RcclApi& nc = rccl();
+                ncclCheck(nc.GroupStart(), "ncclGroupStart");
+                for (const Peer& pr : peers) {
+                    if (pr.recvCount > 0)
+                        ncclCheck(nc.Recv(recvBuf.p + static_cast<size_t>(pr.recvStart) * rows,
+                                          static_cast<size_t>(pr.recvCount) * rows, ncclDouble, pr.rank, comm, commStream),
+                                  "ncclRecv");
+                    if (pr.sendCount > 0)
+                        ncclCheck(nc.Send(sendBuf.p + static_cast<size_t>(pr.sendStart) * rows,
+                                          static_cast<size_t>(pr.sendCount) * rows, ncclDouble, pr.rank, comm, commStream),
+                                  "ncclSend");
+                }
+                ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
             }
-            ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
+            launchUnpack(recvBuf.p, commStream);
+            if (haveA) hipCheck(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
+            launchLserkStage(1, commStream);                   // partition-boundary elements, advance
+            hipCheck(hipEventRecord(evB[cur], commStream), "hipEventRecord");
+            haveA = haveB = true;
         }
-        hipCheck(hipEventRecord(evExchanged, commStream), "hipEventRecord");
-        launchLserkStage(0);                                   // interior elements: overlap the exchange
-        hipCheck(hipStreamWaitEvent(stream, evExchanged, 0), "hipStreamWaitEvent");
-        launchUnpack(recvBuf.p);
-        launchLserkStage(1);                                   // partition-boundary elements, advance
+        // later work on A (dt reduction, downloads, plain stages) sees the last boundary update
+        hipCheck(hipStreamWaitEvent(stream, evB[(numStages - 1) & 1], 0), "hipStreamWaitEvent");
     }
 
     // max (or min) of one double over all ranks, through the device
@@ -753,7 +785,10 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->affineVariant = s->N <= 5 ? 0 : 6;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 6) s->affineVariant = v;
+        if (v >= 0 && v <= 6) {
+            s->affineVariant = v;
+            s->variantForced = true;
+        }
     }
     if (s->affine) {
         s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);
@@ -1322,7 +1357,7 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         std::vector<bdg_sw2d::Peer> peers;
         for (int i = 0; i < num_peers; ++i) {
             const bdg_sw2d::Peer p{peer_ranks[i], send_start[i], send_count[i], recv_start[i], recv_count[i]};
-            if (p.rank < 0 || p.rank >= world || p.rank == rank || p.sendStart < 0 || p.sendCount < 0 ||
+            if (p.rank < 0 || p.rank >= world || p.sendStart < 0 || p.sendCount < 0 ||
                 p.sendStart + p.sendCount > s->numSend || p.recvStart < 0 || p.recvCount < 0 ||
                 p.recvStart + p.recvCount > ghosts)
                 throw arg_error("bdg_sw2d_comm_init: peer ranges do not fit the partition set with bdg_sw2d_set_partition");
@@ -1336,12 +1371,126 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         s->commWorld = world;
         s->peers = peers;
         hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
-        hipCheck(hipEventCreateWithFlags(&s->evPacked, hipEventDisableTiming), "hipEventCreate");
-        hipCheck(hipEventCreateWithFlags(&s->evExchanged, hipEventDisableTiming), "hipEventCreate");
+        // same-device ordering only: no system-scope fence on record (measured: 3 us less per stage)
+        for (hipEvent_t* e : {&s->evA[0], &s->evA[1], &s->evB[0], &s->evB[1]})
+            hipCheck(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate");
         const size_t rows = static_cast<size_t>(s->nf) * s->Np;
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
         s->scalarBuf.alloc(2, s->bytes);
+    });
+}
+
+// ---- in-process group: every part of the split lives in this process (one per GPU of the node, or
+// several on one GPU); the exchange is a device-to-device copy from the neighbour's send buffer. The
+// schedule is the two-chain pipeline of launchLserkStagesExchanged with the RCCL group replaced by
+//   B_r: wait packed(p) -> copy p.send[range towards r] -> r.recv[range from p]   for every neighbour p
+// and the send buffer of a part protected by copied(r) of every neighbour before its next pack.
+int bdg_sw2d_local_peers(bdg_sw2d* s, int rank, const int* peer_ranks, const int* send_start, const int* send_count,
+                         const int* recv_start, const int* recv_count, int num_peers) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_local_peers");
+        if (rank < 0 || num_peers < 0 ||
+            (num_peers > 0 && (!peer_ranks || !send_start || !send_count || !recv_start || !recv_count)))
+            throw arg_error("bdg_sw2d_local_peers: bad argument");
+        if (s->comm || s->localGroup) throw arg_error("bdg_sw2d_local_peers: a transport is already initialised");
+        const int ghosts = s->K - s->numOwned;
+        std::vector<bdg_sw2d::Peer> peers;
+        for (int i = 0; i < num_peers; ++i) {
+            const bdg_sw2d::Peer p{peer_ranks[i], send_start[i], send_count[i], recv_start[i], recv_count[i]};
+            if (p.rank < 0 || p.rank == rank || p.sendStart < 0 || p.sendCount < 0 || p.sendStart + p.sendCount > s->numSend ||
+                p.recvStart < 0 || p.recvCount < 0 || p.recvStart + p.recvCount > ghosts)
+                throw arg_error("bdg_sw2d_local_peers: peer ranges do not fit the partition set with bdg_sw2d_set_partition");
+            peers.push_back(p);
+        }
+        s->use();
+        s->commRank = rank;
+        s->peers = peers;
+        hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
+        for (hipEvent_t* e : {&s->evA[0], &s->evA[1], &s->evB[0], &s->evB[1], &s->evPacked[0], &s->evPacked[1],
+                              &s->evCopied[0], &s->evCopied[1]})
+            hipCheck(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
+        const size_t rows = static_cast<size_t>(s->nf) * s->Np;
+        s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
+        s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
+        s->localGroup = true;
+    });
+}
+
+int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int num_stages) {
+    return guard([&] {
+        if (!parts || num_parts < 1 || num_stages < 0) throw arg_error("bdg_sw2d_group_lserk4_stages: bad argument");
+        for (int r = 0; r < num_parts; ++r) {
+            if (!parts[r] || !parts[r]->localGroup || parts[r]->commRank != r)
+                throw arg_error("bdg_sw2d_group_lserk4_stages: parts[r] must be the part given rank r in bdg_sw2d_local_peers");
+            for (const bdg_sw2d::Peer& pr : parts[r]->peers) {
+                if (pr.rank >= num_parts) throw arg_error("bdg_sw2d_group_lserk4_stages: peer rank outside the group");
+                bool matched = false;
+                for (const bdg_sw2d::Peer& back : parts[pr.rank]->peers)
+                    matched = matched || (back.rank == r && back.sendCount == pr.recvCount && back.recvCount == pr.sendCount);
+                if (!matched) throw arg_error("bdg_sw2d_group_lserk4_stages: neighbour tables of two parts do not match");
+            }
+            if (parts[r]->nf != parts[0]->nf || parts[r]->Np != parts[0]->Np)
+                throw arg_error("bdg_sw2d_group_lserk4_stages: parts differ in order / field count");
+        }
+        if (num_stages == 0) return;
+        const size_t rows = static_cast<size_t>(parts[0]->nf) * parts[0]->Np;
+        for (int r = 0; r < num_parts; ++r) {
+            bdg_sw2d* s = parts[r];
+            s->use();
+            s->dtStage = dt;
+            hipCheck(hipEventRecord(s->evA[1], s->stream), "hipEventRecord");
+            hipCheck(hipStreamWaitEvent(s->commStream, s->evA[1], 0), "hipStreamWaitEvent");
+        }
+        for (int i = 0; i < num_stages; ++i) {
+            const int cur = i & 1, prev = cur ^ 1;
+            const bool first = i == 0;
+            for (int r = 0; r < num_parts; ++r) {           // chain A + pack
+                bdg_sw2d* s = parts[r];
+                s->use();
+                if (!first) hipCheck(hipStreamWaitEvent(s->stream, s->evB[prev], 0), "hipStreamWaitEvent");
+                s->launchLserkStage(0);
+                hipCheck(hipEventRecord(s->evA[cur], s->stream), "hipEventRecord");
+                if (!first)                                   // neighbours are done reading our send buffer
+                    for (const bdg_sw2d::Peer& pr : s->peers)
+                        hipCheck(hipStreamWaitEvent(s->commStream, parts[pr.rank]->evCopied[prev], 0), "hipStreamWaitEvent");
+                s->launchPack(s->sendBuf.p, s->commStream);
+                hipCheck(hipEventRecord(s->evPacked[cur], s->commStream), "hipEventRecord");
+            }
+            for (int r = 0; r < num_parts; ++r) {           // pull the ghosts
+                bdg_sw2d* s = parts[r];
+                s->use();
+                for (const bdg_sw2d::Peer& pr : s->peers) {
+                    if (pr.recvCount == 0) continue;
+                    bdg_sw2d* src = parts[pr.rank];
+                    const bdg_sw2d::Peer* back = nullptr;
+                    for (const bdg_sw2d::Peer& b : src->peers)
+                        if (b.rank == r) back = &b;
+                    hipCheck(hipStreamWaitEvent(s->commStream, src->evPacked[cur], 0), "hipStreamWaitEvent");
+                    hipCheck(hipMemcpyAsync(s->recvBuf.p + static_cast<size_t>(pr.recvStart) * rows,
+                                            src->sendBuf.p + static_cast<size_t>(back->sendStart) * rows,
+                                            static_cast<size_t>(pr.recvCount) * rows * sizeof(double),
+                                            hipMemcpyDeviceToDevice, s->commStream), "ghost copy");
+                }
+                hipCheck(hipEventRecord(s->evCopied[cur], s->commStream), "hipEventRecord");
+            }
+            for (int r = 0; r < num_parts; ++r) {           // chain B: unpack, boundary elements
+                bdg_sw2d* s = parts[r];
+                s->use();
+                s->launchUnpack(s->recvBuf.p, s->commStream);
+                if (!first) hipCheck(hipStreamWaitEvent(s->commStream, s->evA[prev], 0), "hipStreamWaitEvent");
+                s->launchLserkStage(1, s->commStream);
+                hipCheck(hipEventRecord(s->evB[cur], s->commStream), "hipEventRecord");
+            }
+        }
+        for (int r = 0; r < num_parts; ++r) {
+            bdg_sw2d* s = parts[r];
+            s->use();
+            hipCheck(hipStreamWaitEvent(s->stream, s->evB[(num_stages - 1) & 1], 0), "hipStreamWaitEvent");
+            // the neighbours' last copies read this part's send buffer: order them before anything later on A
+            for (const bdg_sw2d::Peer& pr : s->peers)
+                hipCheck(hipStreamWaitEvent(s->stream, parts[pr.rank]->evCopied[(num_stages - 1) & 1], 0), "hipStreamWaitEvent");
+        }
     });
 }
 
@@ -1350,8 +1499,7 @@ int bdg_sw2d_lserk4_stages_exchanged(bdg_sw2d* s, double dt, int num_stages) {
         requireSolver(s, "bdg_sw2d_lserk4_stages_exchanged");
         if (num_stages < 0) throw arg_error("bdg_sw2d_lserk4_stages_exchanged: num_stages < 0");
         s->use();
-        s->dtStage = dt;
-        for (int i = 0; i < num_stages; ++i) s->launchLserkStageExchanged();
+        s->launchLserkStagesExchanged(dt, num_stages);
     });
 }
 

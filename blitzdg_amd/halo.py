@@ -158,7 +158,10 @@ class NativeDistributedSw2d:
     ncclSend/ncclRecv on a communication stream, overlapped with the interior elements, whole
     stage loops issued by one C call (no per-stage Python). PyTorch is not involved."""
 
-    def __init__(self, plan, order, g=9.81, device=0, unique_id=None):
+    def __init__(self, plan, order, g=9.81, device=0, unique_id=None, loopback=False):
+        """loopback=True: schedule rehearsal on ONE GPU -- this process computes `plan.rank`'s share
+        of a `plan.world`-way split, and every neighbour exchange is a send-to-self of the same size
+        (ghost values are then not the neighbours' -- timing only, never results)."""
         import ctypes
         import os
 
@@ -176,6 +179,12 @@ class NativeDistributedSw2d:
         check(lib.bdg_sw2d_set_partition(self.solver._h, plan.num_interior, plan.num_owned, ptr(send), send.size))
 
         id_path = None
+        comm_rank, comm_world = plan.rank, plan.world
+        if loopback:
+            comm_rank, comm_world = 0, 1
+            buf = ctypes.create_string_buffer(128)
+            check(lib.bdg_comm_unique_id(buf, 128))
+            unique_id = buf.raw
         if unique_id is None:
             def make_id():
                 buf = ctypes.create_string_buffer(128)
@@ -189,8 +198,11 @@ class NativeDistributedSw2d:
         pr = arr(peers)
         ss, sc = arr([send_of.get(p, (0, 0))[0] for p in peers]), arr([send_of.get(p, (0, 0))[1] for p in peers])
         rs, rc = arr([recv_of.get(p, (0, 0))[0] for p in peers]), arr([recv_of.get(p, (0, 0))[1] for p in peers])
+        if loopback:
+            pr = arr([0] * len(peers))
+            sc = rc = np.minimum(sc, rc)
         idbuf = ctypes.create_string_buffer(unique_id, 128)
-        check(lib.bdg_sw2d_comm_init(self.solver._h, plan.rank, plan.world, idbuf, ptr(pr), ptr(ss), ptr(sc), ptr(rs),
+        check(lib.bdg_sw2d_comm_init(self.solver._h, comm_rank, comm_world, idbuf, ptr(pr), ptr(ss), ptr(sc), ptr(rs),
                                      ptr(rc), len(peers)))
         self.barrier()
         if id_path is not None and plan.rank == 0:
@@ -201,7 +213,7 @@ class NativeDistributedSw2d:
         self.global_elements = None
 
     @classmethod
-    def box(cls, nx, ny, order, rank, world, g=9.81, device=0, x0=-1.0, x1=1.0, y0=-1.0, y1=1.0):
+    def box(cls, nx, ny, order, rank, world, g=9.81, device=0, x0=-1.0, x1=1.0, y0=-1.0, y1=1.0, loopback=False):
         from . import pyblitzdg as dg
         mesh = dg.MeshManager()
         mesh.buildBoxMesh(nx, ny, x0, x1, y0, y1)
@@ -210,7 +222,7 @@ class NativeDistributedSw2d:
                           bctype=mesh.bcType)
         total = mesh.numElements
         del mesh
-        self = cls(plan, order, g=g, device=device)
+        self = cls(plan, order, g=g, device=device, loopback=loopback)
         self.global_elements = total
         return self
 
@@ -378,3 +390,80 @@ class DistributedSw2d:
         h, hu, hv = self.solver.getState()
         n = self.plan.num_owned
         return self.plan.own_global, h[:, :n], hu[:, :n], hv[:, :n]
+
+
+class LocalGroupSw2d:
+    """All parts of an element split inside ONE process (one per GPU of the node via `devices`, or
+    several on one GPU): same rank-local meshes and the same overlapped two-chain stage schedule as
+    NativeDistributedSw2d, with device-to-device copies instead of RCCL. Besides being the
+    single-process multi-GPU mode, this is how the schedule is verified against a single-domain
+    run on a one-GPU box."""
+
+    def __init__(self, mesh, order, world, g=9.81, devices=None):
+        import ctypes
+
+        from . import pyblitzdg as dg
+        from . import sw2d
+        from ._capi import c_void_p, check, lib, ptr
+
+        self._lib, self._check = lib, check
+        mesh.partitionMesh(world)
+        epart = mesh.elementPartitionMap
+        self.world, self.order = world, order
+        self.global_elements = mesh.numElements
+        self.plans, self.meshes, self.nodes, self.solvers = [], [], [], []
+        arr = lambda vals: np.ascontiguousarray(vals, dtype=np.int32)  # noqa: E731
+        for r in range(world):
+            plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, epart, r, world, bctype=mesh.bcType)
+            lm = build_local_mesh(plan)
+            nd = dg.TriangleNodesProvisioner(order, lm)
+            dev = devices[r] if devices is not None else 0
+            s = sw2d.Sw2dSolver(nodes=nd, g=g, device=dev, flags=sw2d.KEEP_ORDER)
+            send = arr(plan.send_local)
+            check(lib.bdg_sw2d_set_partition(s._h, plan.num_interior, plan.num_owned, ptr(send), send.size))
+            recv_of = {peer: (start, count) for peer, start, count in plan.recv_slices}
+            send_of = {peer: (start, count) for peer, start, count in plan.send_slices}
+            peers = sorted(set(recv_of) | set(send_of))
+            pr = arr(peers)
+            ss, sc = arr([send_of.get(p, (0, 0))[0] for p in peers]), arr([send_of.get(p, (0, 0))[1] for p in peers])
+            rs, rc = arr([recv_of.get(p, (0, 0))[0] for p in peers]), arr([recv_of.get(p, (0, 0))[1] for p in peers])
+            check(lib.bdg_sw2d_local_peers(s._h, r, ptr(pr), ptr(ss), ptr(sc), ptr(rs), ptr(rc), len(peers)))
+            self.plans.append(plan)
+            self.meshes.append(lm)
+            self.nodes.append(nd)
+            self.solvers.append(s)
+        self._handles = (c_void_p * world)(*[s._h for s in self.solvers])
+        self._ctypes = ctypes
+
+    def close(self):
+        for s in self.solvers:
+            s.close()
+        self.solvers = []
+
+    def set_initial_state(self, fn):
+        for nd, s in zip(self.nodes, self.solvers):
+            ctx = nd.dgContext()
+            s.setState(*fn(ctx.x, ctx.y))
+
+    def set_global_state(self, h, hu, hv):
+        for plan, s in zip(self.plans, self.solvers):
+            ids = plan.local_to_global
+            s.setState(h[:, ids], hu[:, ids], hv[:, ids])
+
+    def lserk4_stages(self, dt, nstages):
+        self._check(self._lib.bdg_sw2d_group_lserk4_stages(self._handles, self.world, float(dt), int(nstages)))
+
+    def synchronize(self):
+        for s in self.solvers:
+            s.synchronize()
+
+    def gather_state(self):
+        """Global (Np, K) arrays assembled from every part's owned elements."""
+        Np = self.solvers[0].Np
+        out = [np.empty((Np, self.global_elements)) for _ in range(3)]
+        for plan, s in zip(self.plans, self.solvers):
+            q = s.getState()
+            n = plan.num_owned
+            for o, a in zip(out, q):
+                o[:, plan.own_global] = a[:, :n]
+        return tuple(out)

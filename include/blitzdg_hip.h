@@ -267,7 +267,9 @@ int bdg_sw2d_lserk4_stage_part(bdg_sw2d* s, double dt, int part);
  * with dlopen on first use). Rank 0 creates a 128-byte id and hands it to every rank by any
  * means; each rank then gives its neighbour list: for peer i, it sends the elements
  * send_elements[send_start[i] .. +send_count[i]) (of bdg_sw2d_set_partition) and receives
- * recv_count[i] ghost elements into ghost slots recv_start[i].. (relative to num_owned). */
+ * recv_count[i] ghost elements into ghost slots recv_start[i].. (relative to num_owned).
+ * A peer may be this rank itself (loop-back: the send range is delivered to the receive range on
+ * the same device) -- used to rehearse the per-stage schedule of an N-way split on one GPU. */
 int bdg_comm_unique_id(void* id_out, int capacity);
 int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, const int* peer_ranks,
                        const int* send_start, const int* send_count, const int* recv_start,
@@ -275,6 +277,14 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
 /* num_stages LSERK4 stages with the ghost exchange overlapped with the interior elements:
  * pack -> {grouped ncclSend/ncclRecv on the comm stream || interior kernel} -> unpack -> boundary. */
 int bdg_sw2d_lserk4_stages_exchanged(bdg_sw2d* s, double dt, int num_stages);
+/* In-process alternative to RCCL: all parts of the split are handles of THIS process (one per GPU
+ * of the node, or several on one GPU). bdg_sw2d_local_peers takes the same neighbour tables as
+ * bdg_sw2d_comm_init; bdg_sw2d_group_lserk4_stages then advances parts[0..n) (parts[r] = rank r)
+ * together with the same overlapped schedule, the exchange being device-to-device copies out of the
+ * neighbours' send buffers. */
+int bdg_sw2d_local_peers(bdg_sw2d* s, int rank, const int* peer_ranks, const int* send_start,
+                         const int* send_count, const int* recv_start, const int* recv_count, int num_peers);
+int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int num_stages);
 /* bdg_sw2d_compute_dt with the maxima reduced over all ranks (one 8-byte all-reduce each). */
 int bdg_sw2d_compute_dt_global(bdg_sw2d* s, double cfl, double* dt, double* eta_max);
 int bdg_sw2d_allreduce_max(bdg_sw2d* s, double value, double* out);

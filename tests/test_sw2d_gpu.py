@@ -615,3 +615,26 @@ def test_cpp_driver_sw2d_tidal_matches_oracle_replay(mode, coarse_mesh):
     assert abs(eta_max - np.abs(q[0] - H).max()) / np.abs(q[0] - H).max() < 1e-8
     assert abs(humax - np.abs(q[1]).max()) / np.abs(q[1]).max() < 1e-8
     assert abs(hvmax - np.abs(q[2]).max()) / np.abs(q[2]).max() < 1e-8
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N4", "coarse_box_N6"])
+def test_every_affine_kernel_variant_matches_the_reference_fixture(variant, case, monkeypatch):
+    """The solver picks a kernel family by order and launch size (unrolled vector kernel for large
+    N <= 5 launches, matrix-core kernels for small launches and N >= 6); BDG_SW2D_AFFINE_VARIANT pins
+    one. Every family must reproduce the reference RHS and take LSERK4 stages like the oracle."""
+    monkeypatch.setenv("BDG_SW2D_AFFINE_VARIANT", str(variant))
+    d = load_case(case)
+    s = solver_from_case(d)
+    r = s.computeRHS(d["h"], d["hu"], d["hv"])
+    scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
+    for i in range(3):
+        assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < RHS_TOL
+    o = oracle_from(d)
+    dt = 0.5 * o.dt(d["h"], d["hu"], d["hv"], 0.65, int(d["order"]))
+    s.setState(d["h"], d["hu"], d["hv"])
+    s.lserk4Stages(dt, 7)
+    zero = [np.zeros_like(d["h"]) for _ in range(3)]
+    ref = o.lserk4_stages(d["h"], d["hu"], d["hv"], zero, dt, 0, 7)
+    for a, b in zip(s.getState(), ref[:3]):
+        assert relmax(a, b) < STATE_TOL
