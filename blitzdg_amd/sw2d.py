@@ -239,3 +239,26 @@ def computeRHS(h, hu, hv, g, triangleNodesProvisioner, filter=False, device=0):
         entry = ((float(g), int(device)), Sw2dSolver(nodes=key, g=g, device=device))
         _solver_cache[key] = entry
     return entry[1].computeRHS(h, hu, hv, filter=filter)
+
+
+_script_cache = {}
+
+
+def sw2dComputeRHS(h, hu, hv, hN, g, H, f, ctx):
+    """The four-field RHS of the reference's ``sw2d.py`` script ("variant C", sw2d.py:37-146):
+    ``sw2dComputeRHS(h, hu, hv, hN, g, H, f, ctx) -> (RHS1, RHS2, RHS3, RHS4)`` with tracer ``hN`` and
+    f-plane Coriolis ``f``; ``H`` is accepted and unused, as in the script. ``ctx`` is a DGContext2D
+    (or any object with its attributes, including vmapM / vmapP / BCmap); the device image is cached
+    per (ctx, g, f). Evaluated on the MI355X through the C ABI."""
+    key = (id(ctx), float(g), float(f))
+    entry = _script_cache.get(key)
+    if entry is None:
+        Nfp = int(ctx.numFacePoints)
+        tables = {"order": Nfp - 1, "Dr": ctx.Dr, "Ds": ctx.Ds, "Lift": ctx.Lift, "rx": ctx.rx, "sx": ctx.sx,
+                  "ry": ctx.ry, "sy": ctx.sy, "nx": ctx.nx, "ny": ctx.ny, "Fscale": ctx.Fscale, "vmapM": ctx.vmapM,
+                  "vmapP": ctx.vmapP, "mapW": np.asarray(ctx.BCmap.get(3, []), dtype=np.int32)}
+        entry = (Sw2dSolver(tables=tables, g=g, fields=4, sources={"f": float(f), "CD": 0.0}), ctx)
+        if len(_script_cache) >= 8:
+            _script_cache.pop(next(iter(_script_cache)))
+        _script_cache[key] = entry
+    return entry[0].computeRHS4(h, hu, hv, hN)

@@ -248,3 +248,17 @@ def test_variant_b_host_helpers_match_the_restatement(coarse_mesh):
     ref = onp.build_sponge_coeff(t, e["mapO"], 10.0, 0.6)
     assert np.array_equal(sp, ref) and sp.max() == 10.0 and (sp == 0).any()
     assert np.all(nodes.buildSpongeCoeff([], 10.0, 0.6) == 0)
+
+
+@pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N6"])
+def test_variant_c_numpy_oracle_reproduces_the_reference_script_function(case):
+    """oracle_np.sw2d_rhs_c against the output of sw2dComputeRHS of the reference's sw2d.py script
+    (tests/golden/sw2d_rhsC_*.npz): same NumPy operations in the same order, exact equality."""
+    import os
+
+    from conftest import GOLDEN
+    from oracle.oracle_np import sw2d_rhs_c
+    d = np.load(os.path.join(GOLDEN, f"sw2d_rhsC_{case}.npz"))
+    r = sw2d_rhs_c(d["h"], d["hu"], d["hv"], d["hN"], float(d["g"]), float(d["f"]), d)
+    for i in range(4):
+        assert np.array_equal(r[i], d[f"rhs{i + 1}"])
