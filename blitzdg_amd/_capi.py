@@ -95,6 +95,10 @@ _SIGNATURES = {
     "bdg_trinodes_bcmap_num_tags": (c_int, [_P]),
     "bdg_trinodes_bcmap_tags": (c_int, [_P, POINTER(c_int), c_int]),
     "bdg_trinodes_bcmap_nodes": (c_int, [_P, c_int, POINTER(POINTER(c_int)), POINTER(c_int)]),
+    "bdg_trinodes_split_count": (c_int, [_P]),
+    "bdg_trinodes_split_operators": (c_int, [_P, _P, _P]),
+    "bdg_trinodes_split_elements": (c_int, [_P, _P, _P, _P, _P]),
+    "bdg_trinodes_write_vtu": (c_int, [_P, c_char_p, _P, c_char_p]),
     "bdg_nodes1d_create": (c_int, [c_int, c_int, c_double, c_double, POINTER(_P)]),
     "bdg_nodes1d_destroy": (None, [_P]),
     "bdg_nodes1d_build_nodes": (c_int, [_P]),
@@ -113,6 +117,8 @@ _SIGNATURES = {
     "bdg_sw2d_set_state": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_get_state": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_set_bathymetry": (c_int, [_P, _P]),
+    "bdg_sw2d_output_fields": (c_int, [_P, _P, _P, _P, _P]),
+    "bdg_write_vtu_triangles": (c_int, [c_char_p, _P, _P, _P, c_int, c_char_p]),
     "bdg_sw2d_rhs": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int]),
     "bdg_sw2d_set_state4": (c_int, [_P, _P, _P, _P, _P]),
     "bdg_sw2d_get_state4": (c_int, [_P, _P, _P, _P, _P]),

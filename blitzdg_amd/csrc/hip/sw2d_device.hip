@@ -259,6 +259,7 @@ struct bdg_sw2d {
     bool variantB = false;
     bdg_dev::VbParams vb{};
     DevBuf<double> HxBuf, HyBuf, spongeBuf, lamBuf, vbPartials;
+    DevBuf<double> outM; // (Np, Np) lattice interpolation of the output step
     DevBuf<int> obcBuf;
     double tideAmp = 0.0, tidePeriod = 1.0, tideRamp = 0.0;
     double timeNow = 0.0;  // model time of the resident state (tide phase)
@@ -995,6 +996,25 @@ int bdg_sw2d_get_state(bdg_sw2d* s, double* h, double* hu, double* hv) {
         s->downloadRows(s->qcur, h, s->Np);
         s->downloadRows(s->qcur + pl, hu, s->Np);
         s->downloadRows(s->qcur + 2 * pl, hv, s->Np);
+    });
+}
+
+int bdg_sw2d_output_fields(bdg_sw2d* s, const double* IM, double* eta, double* u, double* v) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_output_fields");
+        s->use();
+        if (IM) {
+            if (!s->outM.p) s->outM.alloc(static_cast<size_t>(s->Np) * s->Np, s->bytes);
+            hipCheck(hipMemcpyAsync(s->outM.p, IM, s->outM.n * sizeof(double), hipMemcpyHostToDevice, s->stream), "H2D copy");
+        }
+        double* targets[3] = {eta, u, v};
+        for (int which = 0; which < 3; ++which) {
+            if (!targets[which]) continue;
+            // aux is scratch between steps (RHS output / RK2 intermediate)
+            hipCheck(s->kt->output(s->qcur, s->hasH ? s->Hbuf.p : nullptr, IM ? s->outM.p : nullptr, s->aux.p, s->ld,
+                                   s->numOwned, which, s->stream), "sw2d_output_kernel");
+            s->downloadRows(s->aux.p, targets[which], s->Np);
+        }
     });
 }
 

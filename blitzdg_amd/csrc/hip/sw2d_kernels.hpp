@@ -333,4 +333,42 @@ __global__ __launch_bounds__(256) void sw2d_dt_kernel(const double* __restrict__
     }
 }
 
+// ------------------------------------------------------------------ output step
+// Primitive output fields of the drivers (eta = h - H, u = hu/h, v = hv/h; reference
+// src/sw2d-simple/main.cpp:123-131, src/sw2d/main.cpp:203-210), optionally interpolated to the
+// equispaced lattice of each element with the (Np, Np) matrix of splitElements
+// (src/TriangleNodesProvisioner.cpp:1154-1180) before they leave the device. Contraction is off and
+// the sum runs over ascending m so the values equal the host's splitElements bit for bit.
+template <int N>
+__global__ __launch_bounds__(256) void sw2d_output_kernel(const double* __restrict__ q, const double* __restrict__ H,
+                                                          const double* __restrict__ M, double* __restrict__ out,
+                                                          long long ld, int K, int which) {
+#pragma clang fp contract(off)
+    using E = Elem<N>;
+    constexpr int Np = E::Np;
+    const long long plane = static_cast<long long>(Np) * ld;
+    const long long k = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    double val[Np];
+#pragma unroll
+    for (int m = 0; m < Np; ++m) {
+        const double h = q[m * ld + k];
+        if (which == 0) val[m] = H ? h - H[m * ld + k] : h;
+        else val[m] = q[which * plane + m * ld + k] / h;
+    }
+    if (!M) {
+#pragma unroll
+        for (int i = 0; i < Np; ++i) out[i * ld + k] = val[i];
+        return;
+    }
+#pragma unroll 1
+    for (int i = 0; i < Np; ++i) {
+        const double* __restrict__ row = M + i * Np;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < Np; ++m) acc = acc + row[m] * val[m];
+        out[i * ld + k] = acc;
+    }
+}
+
 } // namespace bdg_dev

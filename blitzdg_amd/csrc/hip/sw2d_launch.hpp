@@ -32,6 +32,9 @@ struct KernelTable {
     // per-block partial maxima (2 doubles per block of 256 elements)
     hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
                      double* partials, hipStream_t stream);
+    // output step: which = 0 eta (h - H or h), 1 u, 2 v; M = (Np, Np) lattice interpolation or nullptr
+    hipError_t (*output)(const double* q, const double* H, const double* M, double* out, long long ld, int K, int which,
+                         hipStream_t stream);
     // volume node index of face node (f, n), for validating the caller's vmapM
     int (*fmask)(int f, int n);
 };

@@ -196,6 +196,13 @@ hipError_t dt(const double* q, const double* fscale, const double* H, long long 
     return hipGetLastError();
 }
 
+hipError_t output(const double* q, const double* H, const double* M, double* out, long long ld, int K, int which,
+                  hipStream_t stream) {
+    const unsigned grid = static_cast<unsigned>((K + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sw2d_output_kernel<kN>), dim3(grid), dim3(kBlock), 0, stream, q, H, M, out, ld, K, which);
+    return hipGetLastError();
+}
+
 int fmaskOf(int f, int n) { return Elem<kN>::fmask(f, n); }
 
 } // namespace
@@ -208,7 +215,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &stageVb, &dt,
+                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

@@ -5,6 +5,7 @@
 #include "capi_internal.hpp"
 #include "blitzdg/Advec1d.hpp"
 #include "blitzdg/LSERK4.hpp"
+#include "blitzdg/VtkOutputter.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -197,6 +198,65 @@ int bdg_trinodes_sponge_coeff(const bdg_trinodes* nodes, const int* mapO, int nu
                 }
                 coeff[static_cast<size_t>(n) * K + k] = closest < 1.0e12 ? strength * (1.0 - closest / radius) : 0.0;
             }
+    });
+}
+
+// ---- output step (reference splitElements + VtkOutputter)
+int bdg_trinodes_split_count(const bdg_trinodes* nodes) {
+    if (!nodes) return -1;
+    const int N = nodes->prov.get_NOrder();
+    return N * N;
+}
+
+int bdg_trinodes_split_operators(const bdg_trinodes* nodes, double* IM, int* local_triangles) {
+    return guard([&] {
+        if (!nodes || !IM || !local_triangles) throw bdg_detail::arg_error("bdg_trinodes_split_operators: NULL argument");
+        real_matrix_type im;
+        std::vector<index_type> tri;
+        nodes->prov.splitOperators(im, tri);
+        std::copy(im.data(), im.data() + static_cast<size_t>(im.rows()) * im.cols(), IM);
+        std::copy(tri.begin(), tri.end(), local_triangles);
+    });
+}
+
+int bdg_trinodes_split_elements(const bdg_trinodes* nodes, const double* field, double* xnew, double* ynew,
+                                double* fieldnew) {
+    return guard([&] {
+        if (!nodes || !field || !xnew || !ynew || !fieldnew) throw bdg_detail::arg_error("bdg_trinodes_split_elements: NULL argument");
+        const auto& p = nodes->prov;
+        const int Np = p.get_NumLocalPoints(), K = p.get_NumElements();
+        real_matrix_type f(Np, K), xn, yn, fn;
+        std::copy(field, field + static_cast<size_t>(Np) * K, f.data());
+        p.splitElements(p.get_xGrid(), p.get_yGrid(), f, xn, yn, fn);
+        const size_t n = static_cast<size_t>(3) * xn.cols();
+        std::copy(xn.data(), xn.data() + n, xnew);
+        std::copy(yn.data(), yn.data() + n, ynew);
+        std::copy(fn.data(), fn.data() + n, fieldnew);
+    });
+}
+
+int bdg_trinodes_write_vtu(const bdg_trinodes* nodes, const char* path, const double* field, const char* field_name) {
+    return guard([&] {
+        if (!nodes || !path || !field || !field_name) throw bdg_detail::arg_error("bdg_trinodes_write_vtu: NULL argument");
+        const auto& p = nodes->prov;
+        const int Np = p.get_NumLocalPoints(), K = p.get_NumElements();
+        real_matrix_type f(Np, K);
+        std::copy(field, field + static_cast<size_t>(Np) * K, f.data());
+        blitzdg::VtkOutputter(p).writeFieldToFile(path, f, field_name);
+    });
+}
+
+int bdg_write_vtu_triangles(const char* path, const double* x, const double* y, const double* field, int num_triangles,
+                            const char* field_name) {
+    return guard([&] {
+        if (!path || !x || !y || !field || !field_name || num_triangles < 0)
+            throw bdg_detail::arg_error("bdg_write_vtu_triangles: bad argument");
+        real_matrix_type xm(3, num_triangles), ym(3, num_triangles), fm(3, num_triangles);
+        const size_t n = static_cast<size_t>(3) * num_triangles;
+        std::copy(x, x + n, xm.data());
+        std::copy(y, y + n, ym.data());
+        std::copy(field, field + n, fm.data());
+        blitzdg::VtkOutputter::writeTriangles(path, xm, ym, fm, field_name);
     });
 }
 

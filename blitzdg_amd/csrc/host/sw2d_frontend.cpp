@@ -287,6 +287,14 @@ void DeviceSolver::stepSSPRK2(real_type dt, index_type n, bool filter, real_type
     check(bdg_sw2d_step_ssprk2(h_, dt, n, filter ? 1 : 0, spongeCoeff));
 }
 
+void DeviceSolver::outputFields(real_matrix_type& eta, real_matrix_type& u, real_matrix_type& v,
+                                const real_matrix_type* IM) {
+    for (real_matrix_type* m : {&eta, &u, &v})
+        if (m->rows() != Np_ || m->cols() != K_) m->resize(Np_, K_);
+    if (IM && (IM->rows() != Np_ || IM->cols() != Np_)) throw std::runtime_error("outputFields: IM must be (Np, Np)");
+    check(bdg_sw2d_output_fields(h_, IM ? IM->data() : nullptr, eta.data(), u.data(), v.data()));
+}
+
 void DeviceSolver::setTime(real_type t) { check(bdg_sw2d_set_time(h_, t)); }
 
 real_type DeviceSolver::time() const {

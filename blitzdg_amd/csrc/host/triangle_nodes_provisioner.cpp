@@ -513,6 +513,66 @@ void TriangleNodesProvisioner::computeInterpMatrix(const real_vector_type& rout,
     IM = matmul(Vout, Vinv);
 }
 
+void TriangleNodesProvisioner::splitOperators(real_matrix_type& IM, std::vector<index_type>& localE2V) const {
+    const index_type N = NOrder, Np = NumLocalPoints;
+    real_vector_type rout(Np), sout(Np);
+    std::vector<index_type> counter(static_cast<std::size_t>(N + 1) * (N + 1), -1); // -1: no lattice point
+    index_type count = 0;
+    for (index_type n = 0; n < N + 1; ++n)
+        for (index_type m = 0; m < N + 1 - n; ++m) {
+            rout(count) = -1.0 + 2.0 * static_cast<real_type>(m) / static_cast<real_type>(N);
+            sout(count) = -1.0 + 2.0 * static_cast<real_type>(n) / static_cast<real_type>(N);
+            counter[n * (N + 1) + m] = count++;
+        }
+    IM.resize(Np, Np);
+    computeInterpMatrix(rout, sout, IM);
+    localE2V.clear();
+    for (index_type n = 0; n < N; ++n)
+        for (index_type m = 0; m < N - n; ++m) {
+            const index_type v1 = counter[n * (N + 1) + m], v2 = counter[n * (N + 1) + m + 1],
+                             v3 = counter[(n + 1) * (N + 1) + m], v4 = counter[(n + 1) * (N + 1) + m + 1];
+            localE2V.insert(localE2V.end(), {v1, v2, v3});
+            if (v4 >= 0) localE2V.insert(localE2V.end(), {v2, v4, v3});
+        }
+}
+
+void TriangleNodesProvisioner::splitElements(const real_matrix_type& x, const real_matrix_type& y,
+                                             const real_matrix_type& field, real_matrix_type& xnew,
+                                             real_matrix_type& ynew, real_matrix_type& fieldnew) const {
+    const index_type Np = field.rows(), K = field.cols();
+    if (Np != NumLocalPoints || x.rows() != Np || y.rows() != Np || x.cols() != K || y.cols() != K)
+        throw std::runtime_error("splitElements: x, y and field must be (Np, K)");
+    real_matrix_type IM;
+    std::vector<index_type> tri;
+    splitOperators(IM, tri);
+    const index_type nLocal = static_cast<index_type>(tri.size() / 3);
+    auto interpolate = [&](const real_matrix_type& f) { // (Np, Np) x (Np, K), K contiguous
+        real_matrix_type out(Np, K);
+#pragma omp parallel for schedule(static)
+        for (index_type i = 0; i < Np; ++i) {
+            real_type* o = out.data() + static_cast<std::size_t>(i) * K;
+            for (index_type m = 0; m < Np; ++m) {
+                const real_type a = IM(i, m);
+                const real_type* src = f.data() + static_cast<std::size_t>(m) * K;
+                for (index_type k = 0; k < K; ++k) o[k] += a * src[k];
+            }
+        }
+        return out;
+    };
+    const real_matrix_type rx_ = interpolate(x), ry_ = interpolate(y), rf = interpolate(field);
+    xnew.resize(3, nLocal * K);
+    ynew.resize(3, nLocal * K);
+    fieldnew.resize(3, nLocal * K);
+    for (index_type k = 0; k < K; ++k)
+        for (index_type l = 0; l < nLocal; ++l)
+            for (index_type c = 0; c < 3; ++c) {
+                const index_type v = tri[3 * l + c], i = k * nLocal + l;
+                xnew(c, i) = rx_(v, k);
+                ynew(c, i) = ry_(v, k);
+                fieldnew(c, i) = rf(v, k);
+            }
+}
+
 DGContext2D TriangleNodesProvisioner::get_DGContext() const {
     // The gather/scatter maps need a sort over all Np*K nodes and are not read by the
     // RHS path: built eagerly only for small meshes, otherwise on get_gather().

@@ -175,6 +175,24 @@ class TriangleNodesProvisioner:
                                             float(radInfl), C.ptr(out)))
         return out
 
+    def splitElements(self, field):
+        """(xnew, ynew, fieldnew), each (3, N^2*K): the field on N^2 linear triangles per element
+        (reference src/TriangleNodesProvisioner.cpp:1154-1264)."""
+        _, Np, _, K = self._dims()
+        n = lib.bdg_trinodes_split_count(self._h) * K
+        f = C.as_f64(field, (Np, K), "field")
+        out = [np.empty((3, n)) for _ in range(3)]
+        check(lib.bdg_trinodes_split_elements(self._h, C.ptr(f), *[C.ptr(o) for o in out]))
+        return tuple(out)
+
+    def splitOperators(self):
+        """(IM, tri): (Np, Np) interpolation to the equispaced lattice, (N^2, 3) lattice-point indices."""
+        _, Np, _, _ = self._dims()
+        n = lib.bdg_trinodes_split_count(self._h)
+        IM, tri = np.empty((Np, Np)), np.empty((n, 3), dtype=np.int32)
+        check(lib.bdg_trinodes_split_operators(self._h, C.ptr(IM), C.ptr(tri)))
+        return IM, tri
+
     def setCoordinates(self, x, y):
         _, Np, _, K = self._dims()
         xa, ya = C.as_f64(x, (Np, K), "x"), C.as_f64(y, (Np, K), "y")
@@ -258,3 +276,54 @@ def advec1dRun(N=4, K=30, xmin=-1.0, xmax=4.0, c=0.1, CFL=0.8, finalTime=20.0):
     err, steps = c_double(), c_int()
     check(lib.bdg_advec1d_run(N, K, xmin, xmax, c, CFL, finalTime, byref(err), byref(steps)))
     return err.value, steps.value
+
+
+class VtkOutputter:
+    """Writes nodal fields as *.vtu files for Paraview; names of the reference's binding
+    (src/pyblitzdg/pyblitzdg.cpp:189-192). No VTK library involved."""
+
+    def __init__(self, TriangleNodesProvisioner):
+        self._nodes = TriangleNodesProvisioner
+
+    @staticmethod
+    def generateFileName(fieldName, fileNumber):
+        return f"{fieldName}{int(fileNumber):07d}.vtu"
+
+    def writeFieldToFile(self, fileName, field, fieldName):
+        _, Np, _, K = self._nodes._dims()
+        f = C.as_f64(field, (Np, K), "field")
+        check(lib.bdg_trinodes_write_vtu(self._nodes._h, str(fileName).encode(), C.ptr(f), str(fieldName).encode()))
+
+    def writeFieldsToFiles(self, fields, tstep):
+        for name, field in fields.items():
+            self.writeFieldToFile(self.generateFileName(name, tstep), field, name)
+
+    def splitNodes(self):
+        """Coordinates of the small triangles' corners, (3, K*N^2) each (third entry: zeros)."""
+        _, Np, _, K = self._nodes._dims()
+        return self._nodes.splitElements(np.zeros((Np, K)))
+
+    def writeSolverFields(self, solver, tstep, directory="."):
+        """eta, u, v of a device-resident ``sw2d.Sw2dSolver`` to ``<directory>/{eta,u,v}NNNNNNN.vtu``:
+        primitive variables and lattice interpolation happen on the device, the host only cuts the
+        lattice into triangles and writes. Returns the file paths."""
+        import os
+        order, Np, _, K = self._nodes._dims()
+        if not hasattr(self, "_lattice"):
+            IM, tri = self._nodes.splitOperators()
+            ctx = self._nodes.dgContext()
+            if order == 1:
+                self._lattice = (None, lambda a: a, ctx.x, ctx.y)
+            else:
+                cut = lambda a: np.ascontiguousarray(a[tri.T, :].transpose(0, 2, 1).reshape(3, -1))  # noqa: E731
+                xt, yt, _ = self.splitNodes()                    # (3, K*N^2), element-major
+                self._lattice = (IM, cut, xt, yt)
+        IM, cut, xt, yt = self._lattice
+        paths = []
+        for name, lat in zip(("eta", "u", "v"), solver.outputFields(IM)):
+            ft = cut(lat)
+            path = os.path.join(directory, self.generateFileName(name, tstep))
+            check(lib.bdg_write_vtu_triangles(path.encode(), C.ptr(xt), C.ptr(yt), C.ptr(np.ascontiguousarray(ft)),
+                                              ft.shape[1], name.encode()))
+            paths.append(path)
+        return paths

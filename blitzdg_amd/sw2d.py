@@ -156,6 +156,15 @@ class Sw2dSolver:
         check(lib.bdg_sw2d_global_speed(self._h, byref(v)))
         return v.value
 
+    def outputFields(self, IM=None):
+        """(eta, u, v) of the resident state -- eta = h - H (h without bathymetry), u = hu/h, v = hv/h --
+        as (Np, K) arrays; with ``IM`` (from ``nodes.splitOperators()``) interpolated on the device to
+        the equispaced lattice splitElements / the *.vtu writer use."""
+        m = C.as_f64(IM, (self.Np, self.Np), "IM") if IM is not None else None
+        out = [np.empty((self.Np, self.K)) for _ in range(3)]
+        check(lib.bdg_sw2d_output_fields(self._h, C.ptr(m), *[C.ptr(o) for o in out]))
+        return tuple(out)
+
     # ---- RHS (host in, host out)
     def computeRHS(self, h, hu, hv, filter=False):
         h, hu, hv = self._field(h, "h"), self._field(hu, "hu"), self._field(hv, "hv")

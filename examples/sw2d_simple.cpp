@@ -2,11 +2,14 @@
 // written against this repo's headers. Same set-up (mesh, order, filter, Gaussian hump over
 // H = 10, CFL 0.65, midpoint RK2 + filter, adaptive dt, blow-up check, progress line every
 // 10 steps); the time loop runs on the device and the host only reads back for output.
-//   ./bin/sw2d-simple [mesh.msh|box:NXxNY] [order] [finalTime] [maxSteps]
+//   ./bin/sw2d-simple [mesh.msh|box:NXxNY] [order] [finalTime] [maxSteps] [outputDir]
+// With outputDir, eta/u/v are written as *.vtu every 10 steps like the reference (:123-131), from
+// fields computed on the device.
 #include "blitzdg/BlitzHelpers.hpp"
 #include "blitzdg/MeshManager.hpp"
 #include "blitzdg/SW2d.hpp"
 #include "blitzdg/TriangleNodesProvisioner.hpp"
+#include "blitzdg/VtkOutputter.hpp"
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
@@ -18,6 +21,7 @@ int main(int argc, char** argv) {
     const index_type N = argc > 2 ? std::atoi(argv[2]) : 3;
     const real_type finalTime = argc > 3 ? std::atof(argv[3]) : 0.05;
     const index_type maxSteps = argc > 4 ? std::atoi(argv[4]) : 1000000;
+    const std::string outDir = argc > 5 ? argv[5] : "";
     const real_type g = 9.81, CFL = 0.65;
     try {
         MeshManager meshManager;
@@ -47,7 +51,15 @@ int main(int argc, char** argv) {
 
         real_type etaMax = 0, t = 0.0, dt = solver.computeTimeStep(CFL, &etaMax);
         index_type count = 0;
+        VtkOutputter outputter(nodes);
+        real_matrix_type u(Np, K), v(Np, K);
         while (t < finalTime && count < maxSteps) {
+            if ((count % 10) == 0 && !outDir.empty()) {
+                solver.outputFields(eta, u, v);
+                outputter.writeFieldToFile(outDir + "/" + outputter.generateFileName("eta", count), eta, "eta");
+                outputter.writeFieldToFile(outDir + "/" + outputter.generateFileName("u", count), u, "u");
+                outputter.writeFieldToFile(outDir + "/" + outputter.generateFileName("v", count), v, "v");
+            }
             if ((count % 10) == 0) std::cout << "t=" << t << ", eta_max=" << etaMax << ", dt=" << dt << "\n";
             solver.stepRK2(dt, 1, /*filter=*/true);
             dt = solver.computeTimeStep(CFL, &etaMax); // throws on NaN / |eta| > 1e8

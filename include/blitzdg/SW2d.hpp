@@ -92,6 +92,11 @@ public:
                         real_type tidePeriod = 3600 * 12.42, real_type tideRamp = 0.15 / 3600);
     /// Heun steps of the variant-B driver loop (main.cpp:211-236); advances time() by dt per step.
     void stepSSPRK2(real_type dt, index_type numSteps = 1, bool filter = false, real_type spongeCoeff = 0.0);
+    /// Output step: eta = h - H (h without bathymetry), u = hu/h, v = hv/h of the resident state; with
+    /// IM (TriangleNodesProvisioner::splitOperators) interpolated on the device to the equispaced
+    /// lattice the *.vtu writer cuts into triangles.
+    void outputFields(real_matrix_type& eta, real_matrix_type& u, real_matrix_type& v,
+                      const real_matrix_type* IM = nullptr);
     void setTime(real_type t);
     real_type time() const;
     /// dt = CFL / ((N+1)^2 * 0.5 * max|Fscale|*(|u| + sqrt(g h))); throws

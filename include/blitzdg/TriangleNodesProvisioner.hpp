@@ -48,6 +48,14 @@ public:
     void computeWarpFactor(const real_vector_type& r, real_vector_type& warpFactor) const;
     void computeInterpMatrix(const real_vector_type& rout, const real_vector_type& sout,
                              real_matrix_type& IM) const;
+    /// Output step (reference src/TriangleNodesProvisioner.cpp:1154-1264): interpolate a nodal
+    /// field to the equispaced lattice of its element and cut the element into N^2 linear
+    /// triangles; xnew, ynew, fieldnew become (3, N^2*K), one column per small triangle.
+    void splitElements(const real_matrix_type& x, const real_matrix_type& y, const real_matrix_type& field,
+                       real_matrix_type& xnew, real_matrix_type& ynew, real_matrix_type& fieldnew) const;
+    /// The pieces of splitElements: equispaced-lattice interpolation matrix (Np, Np) and the local
+    /// connectivity of the N^2 small triangles (lattice point indices, 3 per triangle).
+    void splitOperators(real_matrix_type& IM, std::vector<index_type>& localE2V) const;
 
     // ---- build steps
     void buildNodes();

@@ -107,6 +107,18 @@ int bdg_trinodes_bcmap_num_tags(const bdg_trinodes* nodes);
 int bdg_trinodes_bcmap_tags(const bdg_trinodes* nodes, int* tags, int capacity);
 int bdg_trinodes_bcmap_nodes(const bdg_trinodes* nodes, int tag, const int** nodes_out, int* count);
 
+/* Output step after the path (reference TriangleNodesProvisioner::splitElements,
+ * src/TriangleNodesProvisioner.cpp:1154-1264, and VtkOutputter, include/VtkOutputter.hpp:30-99).
+ * split_count = N^2 linear triangles per element. split_operators: IM (Np, Np) interpolation to the
+ * equispaced lattice and 3*N^2 lattice-point indices. split_elements: xnew, ynew, fieldnew as
+ * (3, N^2*K). write_vtu: one field to a *.vtu file (raw appended binary; no VTK library). */
+int bdg_trinodes_split_count(const bdg_trinodes* nodes);
+int bdg_trinodes_split_operators(const bdg_trinodes* nodes, double* IM, int* local_triangles);
+int bdg_trinodes_split_elements(const bdg_trinodes* nodes, const double* field, double* xnew, double* ynew,
+                                double* fieldnew);
+int bdg_trinodes_write_vtu(const bdg_trinodes* nodes, const char* path, const double* field,
+                           const char* field_name);
+
 /* ---------------------------------------------------------------- Nodes1DProvisioner
  * reference: include/Nodes1DProvisioner.hpp:25-302 */
 enum {
@@ -184,6 +196,15 @@ int bdg_sw2d_set_state(bdg_sw2d* s, const double* h, const double* hu, const dou
 int bdg_sw2d_get_state(bdg_sw2d* s, double* h, double* hu, double* hv);
 /* Still-water depth H used only by the eta = h - H blow-up check; default: none (check h). */
 int bdg_sw2d_set_bathymetry(bdg_sw2d* s, const double* H);
+
+/* Output step: the drivers' primitive fields eta = h - H (h if no bathymetry was set), u = hu/h,
+ * v = hv/h of the resident state as host (Np, K) arrays; with IM != NULL ((Np, Np), from
+ * bdg_trinodes_split_operators) they are interpolated to each element's equispaced lattice on the
+ * device first (what splitElements does before a *.vtu is written). NULL outputs are skipped. */
+int bdg_sw2d_output_fields(bdg_sw2d* s, const double* IM, double* eta, double* u, double* v);
+/* Writes linear triangles ((3, num_triangles) x, y, field; one column per triangle) as a *.vtu. */
+int bdg_write_vtu_triangles(const char* path, const double* x, const double* y, const double* field,
+                            int num_triangles, const char* field_name);
 
 /* Drop-in for computeRHS: host fields in, host RHS out (upload, one kernel, download).
  * Does not disturb the resident state. filter != 0 applies Filter to the result. */

@@ -341,6 +341,16 @@ def test_cpp_driver_sw2d_simple_matches_oracle_replay(coarse_mesh):
         dt = o.dt(*q, 0.65, 3)
         tt += dt
     assert steps == 25
+    # with an output directory the driver also writes eta/u/v *.vtu every 10 steps (reference :123-131)
+    outdir = os.path.join(root, "gpurun_out", "vtu_test")
+    os.makedirs(outdir, exist_ok=True)
+    out2 = subprocess.run([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), "3", "1e9", "25", outdir],
+                          capture_output=True, text=True, timeout=300)
+    assert out2.returncode == 0, out2.stdout + out2.stderr
+    assert sorted(os.listdir(outdir)) == sorted(f"{n}{c:07d}.vtu" for n in ("eta", "u", "v") for c in (0, 10, 20))
+    assert b"UnstructuredGrid" in open(os.path.join(outdir, "eta0000020.vtu"), "rb").read(300)
+    for f in os.listdir(outdir):
+        os.remove(os.path.join(outdir, f))
     assert abs(t - tt) / tt < 1e-5            # printed with 6 significant digits
     assert abs(humax - np.abs(q[1]).max()) / np.abs(q[1]).max() < 1e-5
     assert abs(eta_max - np.abs(q[0] - 10.0).max()) < 1e-5
@@ -687,3 +697,37 @@ def test_python_driver_sw2d_tracer_matches_oracle_replay():
     for a, b in zip(solver.getState4(), q):
         assert np.abs(a - b).max() / max(np.abs(b).max(), scale) < STATE_TOL
     assert np.abs(q[1]).max() > 1e-4
+
+
+@pytest.mark.parametrize("order", [1, 3, 6])
+def test_output_step_device_fields_and_vtu_files(order, coarse_mesh, tmp_path):
+    """The step after the path: eta, u, v and their interpolation to the equispaced lattice are
+    computed on the device (bdg_sw2d_output_fields); the *.vtu files written from them are
+    byte-identical to the ones the host-only route (splitElements + VtkOutputter, the reference's
+    route) writes for the same state."""
+    nodes = dg.TriangleNodesProvisioner(order, coarse_mesh)
+    t = tables_from_nodes(nodes)
+    h, hu, hv = seeded_fields(t["x"], t["y"])
+    H = 10.0 + 0.1 * t["x"]
+    s = sw2d.Sw2dSolver(nodes=nodes)
+    s.setState(h, hu, hv)
+    eta, u, v = s.outputFields()
+    assert np.array_equal(eta, h) and np.array_equal(u, hu / h) and np.array_equal(v, hv / h)
+    s.setBathymetry(H)
+    eta, u, v = s.outputFields()
+    assert np.array_equal(eta, h - H)
+    out = dg.VtkOutputter(nodes)
+    dev_dir, host_dir = tmp_path / "dev", tmp_path / "host"
+    dev_dir.mkdir()
+    host_dir.mkdir()
+    paths = out.writeSolverFields(s, 3, directory=str(dev_dir))
+    assert [p.split("/")[-1] for p in paths] == ["eta0000003.vtu", "u0000003.vtu", "v0000003.vtu"]
+    for name, field in (("eta", h - H), ("u", hu / h), ("v", hv / h)):
+        ref = host_dir / out.generateFileName(name, 3)
+        out.writeFieldToFile(str(ref), field, name)
+        assert open(ref, "rb").read() == open(dev_dir / ref.name, "rb").read()
+    # after stepping, the output still tracks the resident state
+    dt, _ = s.computeDt(0.5)
+    s.stepLSERK4(dt, 2)
+    h2, hu2, hv2 = s.getState()
+    assert np.array_equal(s.outputFields()[1], hu2 / h2)
