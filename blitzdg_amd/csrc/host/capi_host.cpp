@@ -57,6 +57,13 @@ int bdg_mesh_read(bdg_mesh* mesh, const char* path) {
     });
 }
 
+int bdg_mesh_write(const bdg_mesh* mesh, const char* gmsh_path) {
+    return guard([&] {
+        if (!mesh || !gmsh_path) throw bdg_detail::arg_error("bdg_mesh_write: NULL argument");
+        mesh->mgr.writeMesh(gmsh_path);
+    });
+}
+
 int bdg_mesh_build(bdg_mesh* mesh, const int* etov, int K, const double* vert, int Nv, int dim) {
     return guard([&] {
         if (!mesh || !etov || !vert || K < 1 || Nv < 3) throw bdg_detail::arg_error("bdg_mesh_build: bad argument");

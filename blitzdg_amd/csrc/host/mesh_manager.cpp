@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <fstream>
 #include <iostream>
 #include <numeric>
@@ -145,6 +146,19 @@ void MeshManager::readMesh(const std::string& gmshInputFile) {
     enforceCounterClockwise();
     buildConnectivity();
     buildBCTable(BCTag::Wall);
+}
+
+void MeshManager::writeMesh(const std::string& gmshOutputFile) const {
+    std::FILE* f = std::fopen(gmshOutputFile.c_str(), "w");
+    if (!f) throw std::runtime_error("Unable to open mesh file for writing: " + gmshOutputFile);
+    std::fprintf(f, "$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n", NumVerts);
+    for (index_type v = 0; v < NumVerts; ++v)
+        std::fprintf(f, "%d %.17g %.17g %.17g\n", v + 1, Vert(v * Dim), Vert(v * Dim + 1), Dim > 2 ? Vert(v * Dim + 2) : 0.0);
+    std::fprintf(f, "$EndNodes\n$Elements\n%d\n", NumElements);
+    for (index_type k = 0; k < NumElements; ++k)
+        std::fprintf(f, "%d 2 2 1 1 %d %d %d\n", k + 1, EToV(3 * k) + 1, EToV(3 * k + 1) + 1, EToV(3 * k + 2) + 1);
+    std::fprintf(f, "$EndElements\n");
+    if (std::fclose(f) != 0) throw std::runtime_error("Write failed for mesh file: " + gmshOutputFile);
 }
 
 void MeshManager::readVertices(const std::string& vertFile) {

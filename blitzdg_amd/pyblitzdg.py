@@ -55,6 +55,10 @@ class MeshManager:
     def readMesh(self, gmshInputFile):
         check(lib.bdg_mesh_read(self._h, str(gmshInputFile).encode()))
 
+    def writeMesh(self, gmshOutputFile):
+        """Gmsh 2.2 ASCII of the triangles (the format readMesh takes)."""
+        check(lib.bdg_mesh_write(self._h, str(gmshOutputFile).encode()))
+
     def buildMesh(self, EToV, Vert):
         """EToV: (K, 3) vertex ids (any numeric dtype, as the reference accepts float64);
         Vert: (Nv, 2|3) coordinates."""

@@ -32,6 +32,9 @@ public:
 
     /// Reads a Gmsh 2.2 ASCII .msh file (triangles; quads are rejected here).
     void readMesh(const std::string& gmshInputFile);
+    /// Writes the triangles as Gmsh 2.2 ASCII (two tags per element, coordinates with 17 significant
+    /// digits) -- the format readMesh takes; not in the reference, which only reads.
+    void writeMesh(const std::string& gmshOutputFile) const;
     /// Reads whitespace/comma separated vertex table (rows of Dim reals).
     void readVertices(const std::string& vertFile);
     /// Reads element-to-vertex table (rows of NumFaces 0-based vertex ids).

@@ -77,6 +77,7 @@ enum {
 int bdg_mesh_create(bdg_mesh** out);
 void bdg_mesh_destroy(bdg_mesh* mesh);
 int bdg_mesh_read(bdg_mesh* mesh, const char* gmsh_path);                 /* readMesh   */
+int bdg_mesh_write(const bdg_mesh* mesh, const char* gmsh_path);          /* Gmsh 2.2 ASCII, what readMesh takes */
 int bdg_mesh_build(bdg_mesh* mesh, const int* etov, int num_elements,     /* buildMesh  */
                    const double* vert, int num_verts, int dim);
 int bdg_mesh_build_box(bdg_mesh* mesh, int nx, int ny, double x0, double x1, double y0, double y1,
