@@ -203,7 +203,9 @@ def run_distributed_native(args):
     cap_host_threads(world)
     from blitzdg_amd.halo import NativeDistributedSw2d
 
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    from blitzdg_amd._capi import lib
+    # a launcher may expose one GPU per process (then it is ordinal 0) or all of them (ordinal LOCAL_RANK)
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) % max(1, lib.bdg_device_count())
     d = NativeDistributedSw2d.box(NX, NY, ORDER, rank, world, g=G, device=local_rank)
     try:
         d.set_initial_state(initial_state)
@@ -259,7 +261,7 @@ def run_distributed_torch(args):
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
-    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank))) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     try:

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "bdg_lserk4_b": (POINTER(c_double), []),
     "bdg_advec1d_run": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double,
                                 POINTER(c_double), POINTER(c_int)]),
+    "bdg_device_count": (c_int, []),
     "bdg_sw2d_create": (c_int, [POINTER(Sw2dDesc), POINTER(_P)]),
     "bdg_sw2d_create_from_nodes": (c_int, [_P, c_double, c_int, c_int, POINTER(_P)]),
     "bdg_sw2d_destroy": (None, [_P]),

@@ -936,6 +936,11 @@ void requireSolver(const bdg_sw2d* s, const char* fn) {
 
 extern "C" {
 
+int bdg_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
 int bdg_sw2d_create(const bdg_sw2d_desc* desc, bdg_sw2d** out) {
     return guard([&] {
         if (!desc || !out) throw arg_error("bdg_sw2d_create: NULL argument");

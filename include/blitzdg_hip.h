@@ -187,6 +187,7 @@ typedef struct bdg_sw2d_desc {
                                (straight-sided elements: everything the reference's provisioner
                                builds), one value per element / face is kept instead.      */
 
+int bdg_device_count(void); /* HIP devices visible to this process (0 if none / no driver) */
 int bdg_sw2d_create(const bdg_sw2d_desc* desc, bdg_sw2d** out);
 /* Convenience: take every table from a nodes provisioner (wall nodes = BCmap[3]). */
 int bdg_sw2d_create_from_nodes(const bdg_trinodes* nodes, double g, int device, int flags, bdg_sw2d** out);
