@@ -58,11 +58,11 @@ TriangleNodesProvisioner::TriangleNodesProvisioner(index_type N, const MeshManag
     Drw.resize(Np, Np); Dsw.resize(Np, Np); Filter.resize(Np, Np);
     Lift.resize(Np, Nfaces);
     Fmask.resize(NumFacePoints, NumFaces);
-    xGrid.resize(Np, K); yGrid.resize(Np, K);
-    J.resize(Np, K); rx.resize(Np, K); sx.resize(Np, K); ry.resize(Np, K); sy.resize(Np, K);
-    nx.resize(Nfaces, K); ny.resize(Nfaces, K); Fscale.resize(Nfaces, K);
-    Fx.resize(Nfaces, K); Fy.resize(Nfaces, K);
-    vmapM.resize(Nfaces * K); vmapP.resize(Nfaces * K); mapP.resize(Nfaces * K);
+    // The (rows, K) tables are written entry by entry by buildPhysicalGrid / buildMaps: leave their
+    // first touch to those element-parallel loops instead of zero-filling gigabytes serially here.
+    for (real_matrix_type* m : {&xGrid, &yGrid, &J, &rx, &sx, &ry, &sy}) m->resizeUninitialized(Np, K);
+    for (real_matrix_type* m : {&nx, &ny, &Fscale, &Fx, &Fy}) m->resizeUninitialized(Nfaces, K);
+    for (index_vector_type* v : {&vmapM, &vmapP, &mapP}) v->resizeUninitialized(Nfaces * K);
 
     buildNodes();
     buildLift();

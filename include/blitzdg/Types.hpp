@@ -7,7 +7,11 @@
 // handed to the C-ABI / HIP side as raw pointers with no copies.
 #pragma once
 #include <cstddef>
+#include <memory>
+#include <new>
 #include <stdexcept>
+#include <type_traits>
+#include <utility>
 #include <unordered_map>
 #include <vector>
 
@@ -15,6 +19,23 @@ namespace blitzdg {
 
 using real_type = double;
 using index_type = int;
+
+namespace detail {
+/// std::allocator whose value-less construct() default-initialises (no zero fill), so that
+/// resizeUninitialized() below can leave first touch of a large table to the parallel loop that fills it.
+template <typename T>
+struct default_init_allocator : std::allocator<T> {
+    template <typename U> struct rebind { using other = default_init_allocator<U>; };
+    using std::allocator<T>::allocator;
+    template <typename U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) {
+        ::new (static_cast<void*>(p)) U;
+    }
+    template <typename U, typename... Args> void construct(U* p, Args&&... args) {
+        ::new (static_cast<void*>(p)) U(std::forward<Args>(args)...);
+    }
+};
+template <typename T> using storage = std::vector<T, default_init_allocator<T>>;
+} // namespace detail
 
 /// Dense 1-D array. `length(0)` / `size()` follow the reference's blitz spelling.
 template <typename T>
@@ -33,13 +54,15 @@ public:
     T* data() { return d_.data(); }
     const T* data() const { return d_.data(); }
     void resize(index_type n) { d_.assign(static_cast<std::size_t>(n), T{}); }
+    /// Contents unspecified: for tables every entry of which is written next.
+    void resizeUninitialized(index_type n) { d_.clear(); d_.resize(static_cast<std::size_t>(n)); }
     void fill(T v) { d_.assign(d_.size(), v); }
-    typename std::vector<T>::iterator begin() { return d_.begin(); }
-    typename std::vector<T>::iterator end() { return d_.end(); }
-    typename std::vector<T>::const_iterator begin() const { return d_.begin(); }
-    typename std::vector<T>::const_iterator end() const { return d_.end(); }
+    typename detail::storage<T>::iterator begin() { return d_.begin(); }
+    typename detail::storage<T>::iterator end() { return d_.end(); }
+    typename detail::storage<T>::const_iterator begin() const { return d_.begin(); }
+    typename detail::storage<T>::const_iterator end() const { return d_.end(); }
 private:
-    std::vector<T> d_;
+    detail::storage<T> d_;
 };
 
 /// Dense 2-D array, row-major: element (i,j) at data()[i*cols()+j].
@@ -67,10 +90,16 @@ public:
         r_ = r; c_ = c;
         d_.assign(static_cast<std::size_t>(r) * static_cast<std::size_t>(c), T{});
     }
+    /// Contents unspecified: for tables every entry of which is written next.
+    void resizeUninitialized(index_type r, index_type c) {
+        r_ = r; c_ = c;
+        d_.clear();
+        d_.resize(static_cast<std::size_t>(r) * static_cast<std::size_t>(c));
+    }
     void fill(T v) { d_.assign(d_.size(), v); }
 private:
     index_type r_ = 0, c_ = 0;
-    std::vector<T> d_;
+    detail::storage<T> d_;
 };
 
 using real_vector_type = vector_type<real_type>;
