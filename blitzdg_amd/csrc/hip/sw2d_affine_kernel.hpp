@@ -70,8 +70,24 @@ __device__ __forceinline__ void st_row(T* row, unsigned byteOff, T v) {
     *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byteOff) = v;
 }
 
-template <int N, int MODE>
-__global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParams p) {
+// Source terms evaluated inside the unrolled kernel (PHYS = 1): the momentum sources of the reference's
+// Python RHS (swhelpers/rhs.py:300-309; sw2d.py:140-141) and of its C++ sw2d driver
+// (src/sw2d/main.cpp:461-478) in one form,
+//   S2 = f hv - cd |u| u + slope g h sx,     S3 = -f hu + dragSign cd |u| v + slope g h sy
+// (rhs.py: slope = -1 with sx, sy = zx, zy and dragSign = +1, its sign quirk; main.cpp: slope = +1 with
+// Hx, Hy and dragSign = -1), added node by node: R_c[m] += S_c[m]. PHYS = 2 is the filtered RHS: the
+// reference drivers filter the whole RHS, sources included, so the kernel runs with the PLAIN operators
+// and multiplies the finished R_c by the filter (fmat), instead of the pre-filtered operators of PHYS = 0.
+struct PhysParams {
+    const double* sx;    // (Np, ld) planes or nullptr
+    const double* sy;
+    const double* fcor;  // (Np, ld) Coriolis parameter or nullptr -> fconst
+    const double* fmat;  // [m][i] = F[i][m] or nullptr
+    double fconst, cd, slope, dragSign;
+};
+
+template <int N, int MODE, int PHYS = 0>
+__global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParams p, const PhysParams ph) {
     using E = Elem<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN;
 
@@ -107,6 +123,16 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
         fny[f] = ld_row(ag + (7 + f) * ld, k8);
         fsc[f] = ld_row(ag + (10 + f) * ld, k8);
     }
+    // source planes ride in the same batch and are consumed right away (they seed R2, R3 below)
+    double ssx[PHYS != 0 ? Np : 1], ssy[PHYS != 0 ? Np : 1], sfc[PHYS != 0 ? Np : 1];
+    if constexpr (PHYS != 0) {
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            ssx[i] = ph.sx ? ld_row(ph.sx + i * ld, k8) : 0.0;
+            ssy[i] = ph.sy ? ld_row(ph.sy + i * ld, k8) : 0.0;
+            sfc[i] = ph.fcor ? ld_row(ph.fcor + i * ld, k8) : ph.fconst;
+        }
+    }
     // Keep the loads above in one batch: without this the scheduler sinks each load next to
     // its first use to save registers and the wave pays one memory round trip per node.
     __builtin_amdgcn_sched_barrier(0);
@@ -125,6 +151,17 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     double R1[Np], R2[Np], R3[Np];
 #pragma unroll
     for (int i = 0; i < Np; ++i) R1[i] = R2[i] = R3[i] = 0.0;
+    if constexpr (PHYS != 0) { // momentum sources, node by node
+#pragma unroll
+        for (int m = 0; m < Np; ++m) {
+            const double r = fast_rcp(h[m]);
+            const double u = hu[m] * r, v = hv[m] * r;
+            const double cdn = ph.cd * fast_sqrt(u * u + v * v);
+            const double gh = ph.slope * g * h[m];
+            R2[m] = fma(gh, ssx[m], fma(sfc[m], hv[m], -(cdn * u)));
+            R3[m] = fma(gh, ssy[m], fma(ph.dragSign * cdn, v, -(sfc[m] * hu[m])));
+        }
+    }
 
     // ---- surface term, face by face: R_c[i] += Lift[i][j] * s_c[j]
 #pragma unroll
@@ -223,6 +260,25 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             R2[i] = fma(ds, b2, R2[i]);
             R3[i] = fma(ds, b3, R3[i]);
         }
+    }
+
+    // ---- PHYS == 2: the filtered RHS with sources is Filter * (flux terms + sources); the operators are
+    //      then the plain ones and the filter is applied here, one field at a time
+    if constexpr (PHYS == 2) {
+        auto applyFilter = [&](double (&R)[Np]) {
+            double T[Np];
+#pragma unroll
+            for (int i = 0; i < Np; ++i) T[i] = 0.0;
+#pragma unroll
+            for (int m = 0; m < Np; ++m)
+#pragma unroll
+                for (int i = 0; i < Np; ++i) T[i] = fma(ph.fmat[m * Np + i], R[m], T[i]);
+#pragma unroll
+            for (int i = 0; i < Np; ++i) R[i] = T[i];
+        };
+        applyFilter(R1);
+        applyFilter(R2);
+        applyFilter(R3);
     }
 
     // ---- stage update / output

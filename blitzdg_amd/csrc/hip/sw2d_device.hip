@@ -352,6 +352,23 @@ struct bdg_sw2d {
             vb.tide = tideAmp * std::cos(om * timeNow) * 0.5 * (std::tanh(tideRamp * (timeNow - tidePeriod)) + 1);
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
             hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, st), what);
+        } else if (variantD && fastSources) {
+            // three conserved fields on the unrolled kernel with the sources folded in, the tracer (if
+            // any) by its own one-field-per-wave launch reading the same input state
+            bdg_dev::PhysParams ph{};
+            if (vd.sources) {
+                ph.sx = vd.zx; ph.sy = vd.zy; ph.fcor = vd.fcor;
+                ph.fconst = vd.fconst; ph.cd = vd.cd;
+                ph.slope = -1.0; ph.dragSign = 1.0;   // swhelpers/rhs.py:300-309
+            }
+            // filtered RHS: plain operators, Filter applied to flux terms + sources at the end
+            ph.fmat = filter ? filterT.p : nullptr;
+            p.opsAffine = opsAffine.p;
+            hipCheck(kt->stageAffineSrc(mode, p, ph, st), what);
+            if (nf == 4) { // the tracer has no sources: pre-filtered operators as in variant A
+                p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
+                hipCheck(kt->stageTracer(mode, p, st), what);
+            }
         } else if (variantD) {
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
             hipCheck(kt->stageVd(mode, p, vd, st), what);
@@ -368,6 +385,8 @@ struct bdg_sw2d {
             hipCheck(kt->stage(mode, filter, p, st), what);
         }
     }
+    bool fastSources = false; // variant D on the unrolled kernel (N <= 5) instead of the rolled one
+    DevBuf<double> filterT;   // [m][i] = Filter[i][m], for filtered source terms
     static constexpr int kSmallLaunch = 160000; // elements
     bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
 
@@ -897,6 +916,16 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
             s->vd.zx = plane(d.zx, s->zxBuf);
             s->vd.zy = plane(d.zy, s->zyBuf);
             s->vd.fcor = plane(d.coriolis, s->fcorBuf);
+        }
+        // Measured at C3 (10^6 triangles, N=4): rolled kernel 0.87 ms (3 fields) / 1.16 ms (4 fields) per
+        // stage; unrolled kernel + tracer launch: see DESIGN.md section 3.
+        s->fastSources = s->N <= 5 && !std::getenv("BDG_SW2D_ROLLED_SOURCES");
+        if (s->fastSources && d.Filter) {
+            std::vector<double> ft(static_cast<size_t>(Np) * Np);
+            for (int m = 0; m < Np; ++m)
+                for (int i = 0; i < Np; ++i) ft[static_cast<size_t>(m) * Np + i] = d.Filter[i * Np + m];
+            s->filterT.alloc(ft.size(), s->bytes);
+            hipCheck(hipMemcpy(s->filterT.p, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice), "filter upload");
         }
     }
 

@@ -4,6 +4,7 @@
 #pragma once
 #include "sw2d_affine_kernel.hpp"
 #include "sw2d_vd_kernel.hpp"
+#include "sw2d_tracer_kernel.hpp"
 #include "sw2d_vb_kernel.hpp"
 #include "sw2d_mfma_kernel.hpp"
 #include "sw2d_kernels.hpp"
@@ -25,6 +26,10 @@ struct KernelTable {
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);
+    // unrolled affine kernel + momentum sources (3 fields; N <= 6), the fast path of variants C/D
+    hipError_t (*stageAffineSrc)(int mode, const StageParams& p, const PhysParams& ph, hipStream_t stream);
+    // tracer equation alone (field 3 of a four-field state), unrolled; N <= 6
+    hipError_t (*stageTracer)(int mode, const StageParams& p, hipStream_t stream);
     // variant B (depth, star states, open boundary, global Lax-Friedrichs speed, sources): speed pass over
     // [kbegin, kend) into partials (one double per 256 elements) and *lam, then the fused stage pass
     hipError_t (*stageVb)(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam,

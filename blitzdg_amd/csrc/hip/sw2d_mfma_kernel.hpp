@@ -229,6 +229,10 @@ namespace bdg_dev {
 //     the jump data of only one face is alive while its Lax-Friedrichs speed is reduced;
 //   * the volume term runs in chunks of VC k-steps with the next chunk's state loads in flight;
 //   * the stage update handles one field at a time.
+#ifndef BDG_MFMA2_WAVES
+#define BDG_MFMA2_WAVES 2
+#endif
+
 template <int N>
 struct MfmaOps2 {
     using E = Elem<N>;
@@ -242,7 +246,7 @@ struct MfmaOps2 {
 };
 
 template <int N, int MODE>
-__global__ __launch_bounds__(256, 2) void sw2d_stage_mfma2_kernel(const StageParams p) {
+__global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(const StageParams p) {
     using E = Elem<N>;
     using O = MfmaOps2<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;

@@ -65,8 +65,50 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kBlock), 0, stream, p);
+    hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kBlock), 0, stream, p, PhysParams{});
     return hipGetLastError();
+    }
+}
+
+// unrolled kernel with the momentum source terms (orders where it exists: N <= 6)
+template <int MODE>
+hipError_t launchAffineSrc(const StageParams& p, const PhysParams& ph, hipStream_t stream) {
+    if constexpr (kHighOrder) return hipErrorNotSupported;
+    else {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
+    if (ph.fmat) hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 2>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
+    else hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 1>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
+    return hipGetLastError();
+    }
+}
+
+template <int MODE>
+hipError_t launchTracer(const StageParams& p, hipStream_t stream) {
+    if constexpr (kHighOrder) return hipErrorNotSupported;
+    else {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((sw2d_stage_tracer_kernel<kN, MODE>), dim3(grid), dim3(kBlock), 0, stream, p);
+    return hipGetLastError();
+    }
+}
+
+hipError_t stageTracer(int mode, const StageParams& p, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchTracer<MODE_RHS>(p, stream);
+    case MODE_LSERK: return launchTracer<MODE_LSERK>(p, stream);
+    case MODE_COMBINE: return launchTracer<MODE_COMBINE>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t stageAffineSrc(int mode, const StageParams& p, const PhysParams& ph, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchAffineSrc<MODE_RHS>(p, ph, stream);
+    case MODE_LSERK: return launchAffineSrc<MODE_LSERK>(p, ph, stream);
+    case MODE_COMBINE: return launchAffineSrc<MODE_COMBINE>(p, ph, stream);
+    default: return hipErrorInvalidValue;
     }
 }
 
@@ -137,7 +179,7 @@ hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
     if (p.kend <= p.kbegin) return hipSuccess;
     const size_t ldsBytes = sizeof(double) * MfmaOps2<kN>::DOUBLES;
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
-    const unsigned perCu = static_cast<unsigned>(std::min<size_t>(2, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
+    const unsigned perCu = static_cast<unsigned>(std::min<size_t>(BDG_MFMA2_WAVES, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
     hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
@@ -156,7 +198,7 @@ template <int MODE>
 hipError_t launchVd(const StageParams& p, const VdParams& vp, hipStream_t stream) {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
-    hipLaunchKernelGGL((sw2d_stage_vd_kernel<kN, MODE>), dim3(grid), dim3(64 * vp.nf), 0, stream, p, vp);
+    hipLaunchKernelGGL((sw2d_stage_vd_kernel<kN, MODE>), dim3(grid), dim3(64 * (vp.nf - vp.cbase)), 0, stream, p, vp);
     return hipGetLastError();
 }
 
@@ -215,7 +257,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &stageVb, &dt, &output,
+                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

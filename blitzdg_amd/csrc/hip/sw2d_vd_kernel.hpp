@@ -34,6 +34,7 @@ struct VdParams {
     double cd;             // drag coefficient CD
     int nf;                // 3 or 4 fields
     int sources;           // 0: none (variant A physics, optionally with tracer)
+    int cbase;             // first field this launch computes (wave w owns field cbase + w); 3 = tracer only
 };
 
 template <int N, int MODE>
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void sw2d_stage_vd_kernel(const StageParams
 
     const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
     const unsigned tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
-    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // field of this wave (0..nf-1)
+    const int c = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + vp.cbase; // field of this wave (0..nf-1)
     const unsigned k = static_cast<unsigned>(p.kbegin) + tile * 64u + (threadIdx.x & 63u);
     if (k >= static_cast<unsigned>(p.kend)) return;
     const unsigned k8 = k * 8u, k4 = k * 4u;
