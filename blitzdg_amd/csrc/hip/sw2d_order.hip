@@ -13,6 +13,9 @@ constexpr int kN = BDG_ORDER;
 constexpr int kBlock = 256;
 // Orders above this use the field-split kernels only (3*Np accumulators exceed the VGPR file).
 constexpr bool kHighOrder = BDG_ORDER > 6;
+// The unrolled source-term / tracer kernels are the default only up to this order (createSolver:
+// fastSources); above it they are not instantiated (each costs minutes of compile time at N = 6).
+constexpr bool kNoUnrolledSources = BDG_ORDER > 5;
 
 // Rolled kernels. FIELDS = 1 (three waves per 64 elements, one field each) exists for every
 // order; FIELDS = 3 (all fields per lane) only where 3*Np accumulators fit (N <= 6).
@@ -73,7 +76,7 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
 // unrolled kernel with the momentum source terms (orders where it exists: N <= 6)
 template <int MODE>
 hipError_t launchAffineSrc(const StageParams& p, const PhysParams& ph, hipStream_t stream) {
-    if constexpr (kHighOrder) return hipErrorNotSupported;
+    if constexpr (kNoUnrolledSources) return hipErrorNotSupported;
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
@@ -85,7 +88,7 @@ hipError_t launchAffineSrc(const StageParams& p, const PhysParams& ph, hipStream
 
 template <int MODE>
 hipError_t launchTracer(const StageParams& p, hipStream_t stream) {
-    if constexpr (kHighOrder) return hipErrorNotSupported;
+    if constexpr (kNoUnrolledSources) return hipErrorNotSupported;
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
@@ -114,7 +117,7 @@ hipError_t stageAffineSrc(int mode, const StageParams& p, const PhysParams& ph, 
 
 template <int MODE, int WAVES>
 hipError_t launchStream(const StageParams& p, hipStream_t stream) {
-    if constexpr (kHighOrder) return stageFieldSplit(MODE, p, stream);
+    if constexpr (kNoUnrolledSources) return stageFieldSplit(MODE, p, stream); // A/B variant, N <= 5 only
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
