@@ -347,11 +347,31 @@ struct bdg_sw2d {
         int variant = affineVariant;
         if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < kSmallLaunch) variant = 5;
         if (variantB) {
-            // :352  hP = HM + amp cos(om t) 1/2 (tanh(ramp (t - T)) + 1)
-            const double om = 2.0 * M_PI / tidePeriod;
-            vb.tide = tideAmp * std::cos(om * timeNow) * 0.5 * (std::tanh(tideRamp * (timeNow - tidePeriod)) + 1);
-            p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
-            hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, st), what);
+            vb.tide = tideAt(timeNow);
+            if (fastSources) {
+                // The unrolled kernel also reduces the global speed of the state it writes (for the tide value
+                // the next evaluation is expected to see). If this launch reads exactly that state at exactly
+                // that tide over the whole mesh, the separate speed pass is skipped.
+                p.opsAffine = opsAffine.p;
+                const bool whole = p.kbegin == 0 && p.kend == numOwned;
+                const bool reuse = whole && lamStateFor == p.qin && lamTideFor == vb.tide && !std::getenv("BDG_SW2D_SPEED_PASS");
+                const int cur = lamSlot, nxt = lamSlot ^ 1;
+                vb.lam = reuse ? lamPair.p + cur : lamBuf.p;
+                vb.lamNext = nullptr;
+                lamStateFor = nullptr;
+                if (whole && mode != bdg_dev::MODE_RHS) {
+                    hipCheck(hipMemsetAsync(lamPair.p + nxt, 0, sizeof(double), st), "hipMemset");
+                    vb.lamNext = reinterpret_cast<unsigned long long*>(lamPair.p + nxt);
+                    vb.tideNext = tideAt(nextEvalTime);
+                    lamStateFor = p.qout;
+                    lamTideFor = vb.tideNext;
+                    lamSlot = nxt;
+                }
+                hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, reuse ? 2 : 1, filter ? filterT.p : nullptr, st), what);
+            } else {
+                p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
+                hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 0, nullptr, st), what);
+            }
         } else if (variantD && fastSources) {
             // three conserved fields on the unrolled kernel with the sources folded in, the tracer (if
             // any) by its own one-field-per-wave launch reading the same input state
@@ -387,6 +407,16 @@ struct bdg_sw2d {
     }
     bool fastSources = false; // variant D on the unrolled kernel (N <= 5) instead of the rolled one
     DevBuf<double> filterT;   // [m][i] = Filter[i][m], for filtered source terms
+    // :352  hP = HM + amp cos(om t) 1/2 (tanh(ramp (t - T)) + 1)
+    double tideAt(double t) const {
+        const double om = 2.0 * M_PI / tidePeriod;
+        return tideAmp * std::cos(om * t) * 0.5 * (std::tanh(tideRamp * (t - tidePeriod)) + 1);
+    }
+    DevBuf<double> lamPair;            // two accumulators for the fused next-evaluation speed (alternating)
+    int lamSlot = 0;
+    const double* lamStateFor = nullptr; // state buffer the accumulated speed belongs to (nullptr: none)
+    double lamTideFor = 0.0;
+    double nextEvalTime = 0.0;         // model time of the evaluation that will follow the current launch
     static constexpr int kSmallLaunch = 160000; // elements
     bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
 
@@ -411,10 +441,14 @@ struct bdg_sw2d {
         p.ca = blitzdg::LSERK4::rk4a[s];
         p.cb = blitzdg::LSERK4::rk4b[s];
         p.cc = dtStage;
+        // model time (the tide phase of variant B) is frozen over the five stages and moves on after the last
+        const bool lastOfStep = s == blitzdg::LSERK4::numStages - 1;
+        nextEvalTime = lastOfStep ? timeNow + dtStage : timeNow;
         launchStage(bdg_dev::MODE_LSERK, false, p, "sw2d stage kernel <LSERK>", on);
         if (part == 0 || !advance) return;
         std::swap(qcur, qalt);
         ++stageCount;
+        if (lastOfStep) timeNow += dtStage;
     }
     double dtStage = 0.0;
 
@@ -507,9 +541,11 @@ struct bdg_sw2d {
         bdg_dev::StageParams p = baseParams();
         p.qin = qcur; p.qbase = qcur; p.qout = aux.p;
         p.ca = 1.0; p.cb = 0.0; p.cc = 0.5 * dt;
+        nextEvalTime = timeNow;
         launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
         p.ca = 1.0; p.cb = 0.0; p.cc = dt;
+        nextEvalTime = timeNow + dt;
         launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         std::swap(qcur, qalt);
         timeNow += dt;
@@ -522,10 +558,12 @@ struct bdg_sw2d {
         p.sponge = spongeCoeff;
         p.qin = qcur; p.qbase = qcur; p.qout = aux.p;
         p.ca = 1.0; p.cb = 0.0; p.cc = dt;
+        nextEvalTime = timeNow;                               // second evaluation: same time level (:225)
         launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
         p.ca = 0.5; p.cb = 0.5; p.cc = 0.5 * dt;
-        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>"); // same time level (:225)
+        nextEvalTime = timeNow + dt;                          // first evaluation of the next step
+        launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
         std::swap(qcur, qalt);
         timeNow += dt;
     }
@@ -1016,6 +1054,7 @@ int bdg_sw2d_set_state(bdg_sw2d* s, const double* h, const double* hu, const dou
         s->uploadRows(hv, s->qcur + 2 * pl, s->Np);
         hipCheck(hipMemsetAsync(s->res.p, 0, s->res.n * sizeof(double), s->stream), "hipMemset");
         s->stageCount = 0;
+        s->lamStateFor = nullptr; // a speed accumulated for the previous contents of this buffer is void
         hipCheck(hipStreamSynchronize(s->stream), "set_state sync");
     });
 }
@@ -1082,6 +1121,15 @@ int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* d) {
                 throw arg_error("bdg_sw2d_enable_variant_b: open-boundary node index out of range");
         s->use();
         s->buildSourceOps();
+        s->fastSources = s->N <= 5 && !std::getenv("BDG_SW2D_ROLLED_SOURCES");
+        if (s->fastSources && !s->hostFilter.empty() && !s->filterT.p) {
+            const int Np = s->Np;
+            std::vector<double> ft(static_cast<size_t>(Np) * Np);
+            for (int m = 0; m < Np; ++m)
+                for (int i = 0; i < Np; ++i) ft[static_cast<size_t>(m) * Np + i] = s->hostFilter[static_cast<size_t>(i) * Np + m];
+            s->filterT.alloc(ft.size(), s->bytes);
+            hipCheck(hipMemcpy(s->filterT.p, ft.data(), ft.size() * sizeof(double), hipMemcpyHostToDevice), "filter upload");
+        }
         if (!s->Hbuf.p) s->Hbuf.alloc(s->planeSize(), s->bytes);
         hipCheck(hipMemsetAsync(s->Hbuf.p, 0, s->Hbuf.n * sizeof(double), s->stream), "hipMemset");
         // padding lanes are never computed, but give them a positive depth anyway
@@ -1101,6 +1149,8 @@ int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* d) {
         hipCheck(hipMemcpy(s->obcBuf.p, mask.data(), mask.size() * sizeof(int), hipMemcpyHostToDevice), "open-boundary upload");
         s->vb.obc = s->obcBuf.p;
         if (!s->lamBuf.p) s->lamBuf.alloc(1, s->bytes);
+        if (!s->lamPair.p) s->lamPair.alloc(2, s->bytes);
+        s->lamStateFor = nullptr;
         if (!s->vbPartials.p) s->vbPartials.alloc(static_cast<size_t>((s->K + 255) / 256), s->bytes);
         s->vb.lam = s->lamBuf.p;
         s->vb.fcor = d->coriolis;
@@ -1132,7 +1182,8 @@ int bdg_sw2d_global_speed(bdg_sw2d* s, double* lam) {
         requireSolver(s, "bdg_sw2d_global_speed");
         if (!s->variantB || !lam) throw arg_error("bdg_sw2d_global_speed: variant B is not enabled");
         s->use();
-        hipCheck(hipMemcpyAsync(lam, s->lamBuf.p, sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H copy");
+        hipCheck(hipMemcpyAsync(lam, s->vb.lam ? s->vb.lam : s->lamBuf.p, sizeof(double), hipMemcpyDeviceToHost, s->stream),
+                 "D2H copy");
         hipCheck(hipStreamSynchronize(s->stream), "sync");
     });
 }

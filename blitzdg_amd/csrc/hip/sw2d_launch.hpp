@@ -32,8 +32,10 @@ struct KernelTable {
     hipError_t (*stageTracer)(int mode, const StageParams& p, hipStream_t stream);
     // variant B (depth, star states, open boundary, global Lax-Friedrichs speed, sources): speed pass over
     // [kbegin, kend) into partials (one double per 256 elements) and *lam, then the fused stage pass
+    // unrolled != 0 (N <= 5): the unrolled stage kernel with plain AffineOps in p.opsAffine and the filter
+    // (filterT, [m][i] = F[i][m], or nullptr) applied at the end; otherwise the rolled kernel with a VdOps image
     hipError_t (*stageVb)(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam,
-                          hipStream_t stream);
+                          int unrolled, const double* filterT, hipStream_t stream);
     // per-block partial maxima (2 doubles per block of 256 elements)
     hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
                      double* partials, hipStream_t stream);

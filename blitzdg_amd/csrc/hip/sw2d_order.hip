@@ -214,22 +214,38 @@ hipError_t stageVd(int mode, const StageParams& p, const VdParams& vp, hipStream
     }
 }
 
+// filterT: nullptr = rolled kernel with the operator image in p.opsAffine (VdOps, plain or filtered);
+// otherwise the unrolled kernel (N <= 5) with plain AffineOps in p.opsAffine, and filterT[0] != nullptr ...
 template <int MODE>
-hipError_t launchVb(const StageParams& p, const VbParams& vp, double* partials, double* lam, hipStream_t stream) {
+hipError_t launchVb(const StageParams& p, const VbParams& vp, double* partials, double* lam, int unrolled,
+                    const double* filterT, hipStream_t stream) {
     if (p.kend <= p.kbegin) return hipSuccess;
-    const unsigned nblocks = static_cast<unsigned>((p.kend - p.kbegin + 255) / 256);
-    hipLaunchKernelGGL((sw2d_vb_speed_kernel<kN>), dim3(nblocks), dim3(256), 0, stream, p, vp, partials);
-    hipLaunchKernelGGL((sw2d_vb_speed_reduce_kernel<kN>), dim3(1), dim3(256), 0, stream, partials, static_cast<int>(nblocks), lam);
+    if (unrolled != 2) { // 2: vp.lam already holds the speed of this state (accumulated by the launch that wrote it)
+        const unsigned nblocks = static_cast<unsigned>((p.kend - p.kbegin + 255) / 256);
+        hipLaunchKernelGGL((sw2d_vb_speed_kernel<kN>), dim3(nblocks), dim3(256), 0, stream, p, vp, partials);
+        hipLaunchKernelGGL((sw2d_vb_speed_reduce_kernel<kN>), dim3(1), dim3(256), 0, stream, partials, static_cast<int>(nblocks), lam);
+    }
+    if constexpr (!kNoUnrolledSources) {
+        if (unrolled) {
+            const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
+            if (filterT)
+                hipLaunchKernelGGL((sw2d_stage_vb_unrolled_kernel<kN, MODE, true>), dim3(grid), dim3(kBlock), 0, stream, p, vp, filterT);
+            else
+                hipLaunchKernelGGL((sw2d_stage_vb_unrolled_kernel<kN, MODE, false>), dim3(grid), dim3(kBlock), 0, stream, p, vp, filterT);
+            return hipGetLastError();
+        }
+    }
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
     hipLaunchKernelGGL((sw2d_stage_vb_kernel<kN, MODE>), dim3(grid), dim3(192), 0, stream, p, vp);
     return hipGetLastError();
 }
 
-hipError_t stageVb(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam, hipStream_t stream) {
+hipError_t stageVb(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam, int unrolled,
+                   const double* filterT, hipStream_t stream) {
     switch (mode) {
-    case MODE_RHS: return launchVb<MODE_RHS>(p, vp, partials, lam, stream);
-    case MODE_LSERK: return launchVb<MODE_LSERK>(p, vp, partials, lam, stream);
-    case MODE_COMBINE: return launchVb<MODE_COMBINE>(p, vp, partials, lam, stream);
+    case MODE_RHS: return launchVb<MODE_RHS>(p, vp, partials, lam, unrolled, filterT, stream);
+    case MODE_LSERK: return launchVb<MODE_LSERK>(p, vp, partials, lam, unrolled, filterT, stream);
+    case MODE_COMBINE: return launchVb<MODE_COMBINE>(p, vp, partials, lam, unrolled, filterT, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -29,6 +29,12 @@ struct VbParams {
     const double* sponge;  // (Np, ld) sponge coefficient or nullptr (-> StageParams::sponge)
     double tide;           // open-boundary elevation of this evaluation
     double fcor, cd;
+    // unrolled stage kernel only: the global speed of the NEXT evaluation, accumulated from the state this
+    // launch writes (bit pattern of a non-negative double; atomic max; NaN bit patterns win). The '+' trace of an
+    // interior face is the neighbour's '-' trace, so the maximum over all '-' star states plus the boundary '+'
+    // states is the maximum the speed pass would find. nullptr: do not accumulate.
+    unsigned long long* lamNext;
+    double tideNext;       // open-boundary elevation assumed for that next evaluation
 };
 
 // '-' and '+' traces of one face node after boundary conditions and star states.
@@ -263,6 +269,273 @@ __global__ __launch_bounds__(192, 2) void sw2d_stage_vb_kernel(const StageParams
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- pass 2, unrolled form (N <= 5): the structure of sw2d_stage_affine_kernel -- one lane per element, all
+// three fields, every load in a few large batches, operators through scalar loads -- with variant B's surface
+// term (star states, open boundary, one global speed) and its sources seeded into R2, R3 node by node.
+// FILTERED: the filtered RHS is Filter * (flux terms + sources); the operators are then the plain ones and the
+// filter (vf) multiplies the finished R_c.
+template <int N, int MODE, bool FILTERED>
+__global__ __launch_bounds__(256) void sw2d_stage_vb_unrolled_kernel(const StageParams p, const VbParams vp,
+                                                                      const double* __restrict__ vf) {
+    using E = Elem<N>;
+    constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN;
+
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const unsigned tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    // Lanes past the end redo the last element (identical loads, identical stores) instead of leaving: the
+    // wave-wide maximum at the end of the kernel then never reads a retired lane.
+    const unsigned k = min(static_cast<unsigned>(p.kbegin) + tile * blockDim.x + threadIdx.x, static_cast<unsigned>(p.kend) - 1u);
+    const unsigned k8 = k * 8u, k4 = k * 4u;
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
+    const double* __restrict__ ops = p.opsAffine; // AffineOps<N> image, plain operators
+    const double* __restrict__ qin = p.qin;
+    const double lam = *vp.lam;
+
+    // ---- first batch: gather indices, own state, geometry, depth at the face nodes, bed slopes
+    int idx[NFN];
+#pragma unroll
+    for (int j = 0; j < NFN; ++j) idx[j] = ld_row(p.vmapP + j * ld, k4);
+    const int tags = ld_row(vp.obc, k4);
+    double h[Np], hu[Np], hv[Np];
+#pragma unroll
+    for (int n = 0; n < Np; ++n) {
+        h[n] = ld_row(qin + n * ld, k8);
+        hu[n] = ld_row(qin + plane + n * ld, k8);
+        hv[n] = ld_row(qin + 2 * plane + n * ld, k8);
+    }
+    const double* __restrict__ ag = p.ageo;
+    const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8), sy = ld_row(ag + 3 * ld, k8);
+    double fnx[3], fny[3], fsc[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        fnx[f] = ld_row(ag + (4 + f) * ld, k8);
+        fny[f] = ld_row(ag + (7 + f) * ld, k8);
+        fsc[f] = ld_row(ag + (10 + f) * ld, k8);
+    }
+    double HM[NFN], bx[Np], by[Np];
+#pragma unroll
+    for (int f = 0; f < 3; ++f)
+#pragma unroll
+        for (int n = 0; n < Nfp; ++n) HM[f * Nfp + n] = ld_row(vp.H + E::fmask(f, n) * ld, k8);
+#pragma unroll
+    for (int n = 0; n < Np; ++n) {
+        bx[n] = ld_row(vp.Hx + n * ld, k8);
+        by[n] = ld_row(vp.Hy + n * ld, k8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- second batch: neighbour traces and neighbour depth
+    double hP[NFN], huP[NFN], hvP[NFN], HP[NFN];
+#pragma unroll
+    for (int j = 0; j < NFN; ++j) {
+        const unsigned o8 = static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u;
+        hP[j] = ld_row(qin, o8);
+        huP[j] = ld_row(qin + plane, o8);
+        hvP[j] = ld_row(qin + 2 * plane, o8);
+        HP[j] = ld_row(vp.H, o8);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const double g = p.g, halfg = 0.5 * p.g;
+    double R1[Np], R2[Np], R3[Np];
+    // ---- sources (main.cpp:461-478): RHS2 += g h Hx - CD u|u| + f hv;  RHS3 += g h Hy - CD v|u| - f hu
+#pragma unroll
+    for (int m = 0; m < Np; ++m) {
+        const double r = fast_rcp(h[m]);
+        const double u = hu[m] * r, v = hv[m] * r;
+        const double cdn = vp.cd * fast_sqrt(u * u + v * v);
+        const double gh = g * h[m];
+        R1[m] = 0.0;
+        R2[m] = fma(gh, bx[m], fma(vp.fcor, hv[m], -(cdn * u)));
+        R3[m] = fma(gh, by[m], -fma(vp.fcor, hu[m], cdn * v));
+    }
+
+    // ---- surface term with star states, face by face
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const double nxf = fnx[f], nyf = fny[f], half_fs = 0.5 * fsc[f];
+#pragma unroll
+        for (int n = 0; n < Nfp; ++n) {
+            const int j = f * Nfp + n, m = E::fmask(f, n);
+            double hq = hP[j], huq = huP[j], hvq = hvP[j];
+            if ((tags >> j) & 1) {         // open boundary: surface follows the tide (:348-353)
+                huq = hu[m];
+                hvq = hv[m];
+                hq = HM[j] + vp.tide;
+            } else if (idx[j] < 0) {       // reflective wall (:340-345)
+                const double un = hu[m] * nxf + hv[m] * nyf;
+                hq = h[m];
+                huq = hu[m] - 2 * nxf * un;
+                hvq = hv[m] - 2 * nyf * un;
+            }
+            const double bM = -HM[j], bP = -HP[j], mx = fmax(bP, bM);
+            const double hMs = fmax(0.0, h[m] + bM - mx), hPs = fmax(0.0, hq + bP - mx);
+            const double rM = fast_rcp(hMs), rP = fast_rcp(hPs);
+            const double huMs = hMs * (hu[m] * rM), hvMs = hMs * (hv[m] * rM);   // hMstar*(huM/hM), hM = hMstar
+            const double huPs = hPs * (huq * rP), hvPs = hPs * (hvq * rP);
+            const double uM = huMs * rM, vM = hvMs * rM, uP = huPs * rP, vP = hvPs * rP;
+            const double prM = halfg * hMs * hMs, prP = halfg * hPs * hPs;
+            const double F2M = huMs * uM + prM, G2M = huMs * vM, G3M = hvMs * vM + prM;
+            const double F2P = huPs * uP + prP, G2P = huPs * vP, G3P = hvPs * vP + prP;
+            const double dh = hMs - hPs, dhu = huMs - huPs, dhv = hvMs - hvPs;
+            const double s1 = half_fs * (dhu * nxf + dhv * nyf - lam * dh);
+            const double s2 = half_fs * ((F2M - F2P) * nxf + (G2M - G2P) * nyf - lam * dhu);
+            const double s3 = half_fs * ((G2M - G2P) * nxf + (G3M - G3P) * nyf - lam * dhv);
+#pragma unroll
+            for (int i = 0; i < Np; ++i) {
+                const double lj = ops[AffineOps<N>::OFF_LIFT + j * Np + i];
+                R1[i] = fma(lj, s1, R1[i]);
+                R2[i] = fma(lj, s2, R2[i]);
+                R3[i] = fma(lj, s3, R3[i]);
+            }
+        }
+    }
+
+    // ---- stage inputs needed at the very end: issue now, land during the volume loop
+    double old1[Np], old2[Np], old3[Np];
+    if constexpr (MODE != MODE_RHS) {
+        const double* __restrict__ b2 = (MODE == MODE_LSERK) ? p.res : p.qbase;
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            old1[i] = ld_row(b2 + i * ld, k8);
+            old2[i] = ld_row(b2 + plane + i * ld, k8);
+            old3[i] = ld_row(b2 + 2 * plane + i * ld, k8);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- volume term
+#pragma unroll
+    for (int m = 0; m < Np; ++m) {
+        const double r = fast_rcp(h[m] * p.one);
+        const double u = hu[m] * r, v = hv[m] * r;
+        const double pr = halfg * h[m] * h[m];
+        const double F2 = hu[m] * u + pr, G2 = hu[m] * v, G3 = hv[m] * v + pr;
+        const double a1 = -(rx * hu[m] + ry * hv[m]), b1 = -(sx * hu[m] + sy * hv[m]);
+        const double a2 = -(rx * F2 + ry * G2), b2 = -(sx * F2 + sy * G2);
+        const double a3 = -(rx * G2 + ry * G3), b3 = -(sx * G2 + sy * G3);
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            const double dr = ops[AffineOps<N>::OFF_D + 2 * (m * Np + i)];
+            R1[i] = fma(dr, a1, R1[i]);
+            R2[i] = fma(dr, a2, R2[i]);
+            R3[i] = fma(dr, a3, R3[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            const double ds = ops[AffineOps<N>::OFF_D + 2 * (m * Np + i) + 1];
+            R1[i] = fma(ds, b1, R1[i]);
+            R2[i] = fma(ds, b2, R2[i]);
+            R3[i] = fma(ds, b3, R3[i]);
+        }
+    }
+
+    if constexpr (FILTERED) {
+        auto applyFilter = [&](double (&R)[Np]) {
+            double T[Np];
+#pragma unroll
+            for (int i = 0; i < Np; ++i) T[i] = 0.0;
+#pragma unroll
+            for (int m = 0; m < Np; ++m)
+#pragma unroll
+                for (int i = 0; i < Np; ++i) T[i] = fma(vf[m * Np + i], R[m], T[i]);
+#pragma unroll
+            for (int i = 0; i < Np; ++i) R[i] = T[i];
+        };
+        applyFilter(R1);
+        applyFilter(R2);
+        applyFilter(R3);
+    }
+
+    // ---- stage update / output
+    if constexpr (MODE == MODE_RHS) {
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            st_row(p.rhs + i * ld, k8, R1[i]);
+            st_row(p.rhs + plane + i * ld, k8, R2[i]);
+            st_row(p.rhs + 2 * plane + i * ld, k8, R3[i]);
+        }
+    } else if constexpr (MODE == MODE_LSERK) {
+        const double a = p.ca, b = p.cb, dt = p.cc;
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            const double n1 = a * old1[i] + dt * R1[i], n2 = a * old2[i] + dt * R2[i], n3 = a * old3[i] + dt * R3[i];
+            st_row(p.res + i * ld, k8, n1);
+            st_row(p.res + plane + i * ld, k8, n2);
+            st_row(p.res + 2 * plane + i * ld, k8, n3);
+            h[i] += b * n1;
+            hu[i] += b * n2;
+            hv[i] += b * n3;
+            st_row(p.qout + i * ld, k8, h[i]);
+            st_row(p.qout + plane + i * ld, k8, hu[i]);
+            st_row(p.qout + 2 * plane + i * ld, k8, hv[i]);
+        }
+    } else {
+        const double a = p.ca, b = p.cb, c = p.cc;
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            const double sp = vp.sponge ? ld_row(vp.sponge + i * ld, k8) : p.sponge;
+            h[i] = a * old1[i] + b * h[i] + c * R1[i];
+            hu[i] = sponge_relax(a * old2[i] + b * hu[i] + c * R2[i], sp);
+            hv[i] = sponge_relax(a * old3[i] + b * hv[i] + c * R3[i], sp);
+            st_row(p.qout + i * ld, k8, h[i]);
+            st_row(p.qout + plane + i * ld, k8, hu[i]);
+            st_row(p.qout + 2 * plane + i * ld, k8, hv[i]);
+        }
+    }
+
+    // ---- global speed of the next evaluation from the state just written (h, hu, hv now hold it)
+    if constexpr (MODE != MODE_RHS) {
+        if (vp.lamNext) {
+            double best = 0.0;
+            bool bad = false;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const double nxf = fnx[f], nyf = fny[f];
+#pragma unroll
+                for (int n = 0; n < Nfp; ++n) {
+                    const int j = f * Nfp + n, m = E::fmask(f, n);
+                    const double HMj = ld_row(vp.H + m * ld, k8);
+                    const double HPj = ld_row(vp.H, static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u);
+                    const double bM = -HMj, bP = -HPj, mx = fmax(bP, bM);
+                    const double hMs = fmax(0.0, h[m] + bM - mx);
+                    const double rM = fast_rcp(hMs);
+                    const double huMs = hMs * (hu[m] * rM), hvMs = hMs * (hv[m] * rM);
+                    const double uM = huMs * rM, vM = hvMs * rM;
+                    double spd = sqrt(uM * uM + vM * vM) + sqrt(g * hMs);
+                    const bool open = (tags >> j) & 1;
+                    if (open || idx[j] < 0) { // boundary: the '+' state is built from the element's own
+                        double hq = h[m], huq = hu[m], hvq = hv[m];
+                        if (open) hq = HMj + vp.tideNext;
+                        else {
+                            const double un = hu[m] * nxf + hv[m] * nyf;
+                            huq = hu[m] - 2 * nxf * un;
+                            hvq = hv[m] - 2 * nyf * un;
+                        }
+                        const double hPs = fmax(0.0, hq + bP - mx);
+                        const double rP = fast_rcp(hPs);
+                        const double huPs = hPs * (huq * rP), hvPs = hPs * (hvq * rP);
+                        const double uP = huPs * rP, vP = hvPs * rP;
+                        const double spdP = sqrt(uP * uP + vP * vP) + sqrt(g * hPs);
+                        if (spdP != spdP) bad = true;
+                        spd = fmax(spd, spdP);
+                    }
+                    if (spd != spd) bad = true;
+                    best = fmax(best, spd);
+                }
+            }
+            if (bad) best = __builtin_nan("");
+            unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(best));
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long other = __shfl_xor(bits, off);
+                bits = other > bits ? other : bits;
+            }
+            if ((threadIdx.x & 63u) == 0u) atomicMax(vp.lamNext, bits);
         }
     }
 }

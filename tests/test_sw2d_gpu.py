@@ -731,3 +731,47 @@ def test_output_step_device_fields_and_vtu_files(order, coarse_mesh, tmp_path):
     s.stepLSERK4(dt, 2)
     h2, hu2, hv2 = s.getState()
     assert np.array_equal(s.outputFields()[1], hu2 / h2)
+
+
+@pytest.mark.parametrize("order", [3, 6])
+def test_variant_b_lserk4_and_fused_speed_reduction(order, coarse_mesh, monkeypatch):
+    """Variant B under LSERK4: the tide phase is frozen over the five stages of a step and advances after
+    the last one. At N <= 5 the stage kernel also reduces the global speed of the state it writes, so the
+    next evaluation skips the separate speed pass; forcing the pass (BDG_SW2D_SPEED_PASS=1) must give the
+    same states to round-off, and both must follow the NumPy replay."""
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    from oracle import lserk4_coefficients
+    nodes, t, e = variant_b_setup(order, coarse_mesh)
+    Hx, Hy = nodes.bedSlopes(e["H"])
+    t0 = 0.9 * onp.TIDE_PERIOD            # inside the tanh ramp: the tide changes from step to step
+    e = {**e, "time": t0}
+
+    def run():
+        s = _variant_b_solver(nodes, e, Hx, Hy)
+        s.setState(e["h"], e["hu"], e["hv"])
+        dt, _ = s.computeDt(0.3)
+        s.lserk4Stages(dt, 12)             # two full steps and two stages of a third
+        return s.getState(), dt, s.time
+
+    (got, dt, t_end) = run()
+    monkeypatch.setenv("BDG_SW2D_SPEED_PASS", "1")
+    (forced, dt2, _) = run()
+    assert dt2 == dt
+    for a, b in zip(got, forced):
+        assert relmax(a, b) < 1e-13
+    a_, b_ = lserk4_coefficients()
+    q = [e["h"].copy(), e["hu"].copy(), e["hv"].copy()]
+    res = [np.zeros_like(x) for x in q]
+    time = t0
+    for stage in range(12):
+        s5 = stage % 5
+        r = onp.sw2d_rhs_b(*q, e["H"], Hx, Hy, 9.81, e["f"], e["CD"], time, t, e["mapO"])
+        for c in range(3):
+            res[c] = a_[s5] * res[c] + dt * r[c]
+            q[c] = q[c] + b_[s5] * res[c]
+        if s5 == 4:
+            time += dt
+    assert abs(t_end - time) < 1e-9 * time
+    for a, b in zip(got, q):
+        assert relmax(a, b) < STATE_TOL
