@@ -282,6 +282,17 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
 #pragma unroll
             for (int r = 0; r < MT; ++r) acc[c][r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
 
+        // gather indices of all three faces: issued before the volume term so that each face's dependent
+        // trace gathers can start the moment its turn comes (N=8, 250 k elements: 0.418 -> 0.394 ms)
+        int fidx[3][KF];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const int n = 4 * tf + static_cast<int>(q);
+                fidx[f][tf] = n < Nfp ? ld_row(p.vmapP + (f * Nfp + n) * ld, k4) : 0;
+            }
+
         // ---- volume term in chunks of VC k-steps, next chunk's loads in flight
         {
             const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
@@ -349,8 +360,8 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                 const int n = 4 * tf + static_cast<int>(q);
                 e1[tf] = e2[tf] = e3[tf] = d1[tf] = d2[tf] = d3[tf] = 0.0;
                 if (n < Nfp) {
-                    const int jf = f * Nfp + n, m = fmask_rt<N>(f, n);
-                    const int id = ld_row(p.vmapP + jf * ld, k4);
+                    const int m = fmask_rt<N>(f, n);
+                    const int id = fidx[f][tf];
                     const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
                                  hvM = ld_row(qin + 2 * plane + m * ld, k8);
                     const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
