@@ -167,3 +167,36 @@ def test_overlapped_two_chain_schedule_matches_single_domain(order, world, shape
         assert np.abs(ref[1] - q0[1]).max() > 1e-4
     finally:
         group.close()
+
+
+def _run_bench(args, env_extra):
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_distributed_entry_point_with_native_rccl_single_rank():
+    """bench.py the way the driver launches it for N > 1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment), here with one rank: the library's own RCCL communicator, file rendezvous, two-stream stage
+    loop, global dt reduction, one JSON line from rank 0."""
+    d = _run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5", "--cells", "60x40"],
+                   {"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(_free_port()), "BDG_BENCH_FORCE_DISTRIBUTED": "1"})
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["elements"] == 4800
+
+
+def test_bench_loopback_rehearsal_of_an_eight_way_split():
+    """The RCCL exchange path with real message sizes and neighbour counts, on one GPU: rank r's share of an
+    8-way split with every neighbour exchange a send-to-self (timing aid; the state is not physical)."""
+    d = _run_bench(["--rehearse-world", "8", "--steps", "30", "--warmup", "5", "--cells", "160x80"],
+                   {"BDG_REHEARSE_RANKS": "0,5"})
+    assert d["rehearsal"] and d["world"] == 8 and [r["rank"] for r in d["ranks"]] == [0, 5]
+    for r in d["ranks"]:
+        assert r["owned"] == 3200 and r["ghost"] > 0 and r["peers"] >= 1 and 0 < r["ms_per_stage"] < 5
