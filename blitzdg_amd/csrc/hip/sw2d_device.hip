@@ -345,7 +345,7 @@ struct bdg_sw2d {
         // instead of 64 (measured at N=4: 750 elements 7 us vs 19 us; 125 k elements 48 us vs 56 us;
         // 250 k elements 136 us vs 109 us -- DESIGN.md section 4).
         int variant = affineVariant;
-        if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < kSmallLaunch) variant = 5;
+        if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < kSmallLaunch[N]) variant = 5;
         if (variantB) {
             vb.tide = tideAt(timeNow);
             if (fastSources) {
@@ -417,7 +417,9 @@ struct bdg_sw2d {
     const double* lamStateFor = nullptr; // state buffer the accumulated speed belongs to (nullptr: none)
     double lamTideFor = 0.0;
     double nextEvalTime = 0.0;         // model time of the evaluation that will follow the current launch
-    static constexpr int kSmallLaunch = 160000; // elements
+    // elements below which the matrix-core kernel is the faster one, per order (measured crossovers:
+    // N=2 between 30 k and 61 k, N=3 near 125 k, N=4 between 125 k and 250 k, N=5 near 61 k; N=1 never ahead)
+    static constexpr int kSmallLaunch[6] = {0, 4000, 40000, 100000, 160000, 60000};
     bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
 
     void launchRhs(const double* qin, double* out, bool filter) {
