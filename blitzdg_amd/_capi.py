@@ -110,6 +110,7 @@ _SIGNATURES = {
     "bdg_lserk4_num_stages": (c_int, []),
     "bdg_lserk4_a": (POINTER(c_double), []),
     "bdg_lserk4_b": (POINTER(c_double), []),
+    "bdg_nodes1d_advec_rhs": (c_int, [_P, _P, c_double, _P]),
     "bdg_advec1d_run": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double,
                                 POINTER(c_double), POINTER(c_int)]),
     "bdg_device_count": (c_int, []),

@@ -409,6 +409,18 @@ int bdg_lserk4_num_stages(void) { return LSERK4::numStages; }
 const double* bdg_lserk4_a(void) { return LSERK4::rk4a; }
 const double* bdg_lserk4_b(void) { return LSERK4::rk4b; }
 
+int bdg_nodes1d_advec_rhs(bdg_nodes1d* nodes, const double* u, double c, double* rhs) {
+    return guard([&] {
+        if (!nodes || !u || !rhs) throw bdg_detail::arg_error("bdg_nodes1d_advec_rhs: NULL argument");
+        auto& p = nodes->prov;
+        const int Np = p.get_NumLocalPoints(), K = p.get_NumElements();
+        real_matrix_type um(Np, K), out(Np, K);
+        std::copy(u, u + static_cast<size_t>(Np) * K, um.data());
+        blitzdg::advec1d::computeRHS(um, c, p, out);
+        std::copy(out.data(), out.data() + static_cast<size_t>(Np) * K, rhs);
+    });
+}
+
 int bdg_advec1d_run(int order, int K, double xmin, double xmax, double c, double cfl, double final_time,
                     double* max_error, int* num_steps) {
     return guard([&] {

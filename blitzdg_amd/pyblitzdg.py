@@ -274,6 +274,17 @@ class Nodes1DProvisioner:
     mapO = property(lambda self: lib.bdg_nodes1d_map_o(self._h))
 
 
+def advec1dComputeRHS(u, c, nodes1d):
+    """The reference script's ``advec1dComputeRHS(u, c, nodes1d)`` (advec1d.py:12-39; C++:
+    src/advec1d/main.cpp:126-188): upwind flux, outflow at mapO, zero inflow at mapI. Host code --
+    advec1d is the CPU plumbing configuration."""
+    Np, K = nodes1d.numLocalPoints, nodes1d.numElements
+    ua = C.as_f64(u, (Np, K), "u")
+    out = np.empty((Np, K))
+    check(lib.bdg_nodes1d_advec_rhs(nodes1d._h, C.ptr(ua), float(c), C.ptr(out)))
+    return out
+
+
 def advec1dRun(N=4, K=30, xmin=-1.0, xmax=4.0, c=0.1, CFL=0.8, finalTime=20.0):
     """The reference's bin/advec1d (src/advec1d/main.cpp:35-122) with N, K as arguments;
     host-only LSERK4 loop. Returns (max-norm error vs exact, number of steps)."""

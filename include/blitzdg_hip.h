@@ -143,6 +143,9 @@ const double* bdg_lserk4_b(void);
 /* advec1d: CPU plumbing config (reference src/advec1d/main.cpp:35-122). Runs the
  * LSERK4 loop on the host to t >= final_time and returns the max-norm error
  * against the translated Gaussian. No GPU involved. */
+/* advec1d::computeRHS(u, c, nodes1D, RHS) (reference src/advec1d/main.cpp:126-188; Python twin
+ * advec1d.py:12-39) on the host: u, rhs are (Np, K). buildNodes and computeJacobian must have run. */
+int bdg_nodes1d_advec_rhs(bdg_nodes1d* nodes, const double* u, double c, double* rhs);
 int bdg_advec1d_run(int order, int num_elements, double xmin, double xmax, double c, double cfl,
                     double final_time, double* max_error, int* num_steps);
 

@@ -22,6 +22,7 @@ Writes
                             hN = 0, f = CD = 0, zx = zy = 0  (variant D == variant A up
                             to round-off)
   sw2d_rhs4_<case>.npz      the same function with tracer, Coriolis array, drag and bed slope
+  advec1d_rhs_N4_K100.npz   advec1dComputeRHS(u, c, nodes1d) of the reference SCRIPT advec1d.py:12-39
   sw2d_rhsC_<case>.npz      sw2dComputeRHS(h,hu,hv,hN,g,H,f,ctx) of the reference SCRIPT sw2d.py:37-146
                             ("variant C"), its two function definitions compiled on their own
 """
@@ -199,6 +200,27 @@ def rhsC_case(name, mesh, order, g=9.81 * 0.0025, f=7.88e-5):
           f"{max(abs(a).max() for a in r):.6g}")
 
 
+def advec1d_case(order=4, K=100, xmin=-1.0, xmax=4.0, c=0.1):
+    """advec1dComputeRHS(u, c, nodes1d) of the reference SCRIPT advec1d.py:12-39 on BASELINE config 1
+    (N=4, K=100, [-1, 4]), fed with this repo's Nodes1DProvisioner tables; a Gaussian and a seeded field."""
+    import blitzdg_amd.pyblitzdg as dg
+    scope = script_functions(os.path.join(REF, "advec1d.py"), ("advec1dComputeRHS",))
+    nodes = dg.Nodes1DProvisioner(order, K, xmin, xmax)
+    nodes.buildNodes()
+    nodes.computeJacobian()
+    tabs = {k: getattr(nodes, k) for k in ("Dr", "Lift", "rx", "Fscale", "nx", "vmapM", "vmapP", "xGrid")}
+    ref_nodes = types.SimpleNamespace(mapI=nodes.mapI, mapO=nodes.mapO, **tabs)
+    x = tabs["xGrid"]
+    rng = np.random.default_rng(5)
+    u1 = np.exp(-10 * x * x)
+    u2 = u1 + 0.1 * rng.standard_normal(x.shape)
+    r1 = scope["advec1dComputeRHS"](u1, c, ref_nodes)
+    r2 = scope["advec1dComputeRHS"](u2, c, ref_nodes)
+    np.savez_compressed(os.path.join(HERE, "advec1d_rhs_N4_K100.npz"), order=order, K=K, xmin=xmin, xmax=xmax, c=c,
+                        u1=u1, u2=u2, rhs1=r1, rhs2=r2, mapI=nodes.mapI, mapO=nodes.mapO, **tabs)
+    print(f"advec1d_rhs_N4_K100.npz: |rhs|max={max(abs(r1).max(), abs(r2).max()):.6g}")
+
+
 def main():
     import blitzdg_amd.pyblitzdg as dg
     shutil.copyfile(os.path.join(REF, "input/coarse_box.msh"), os.path.join(HERE, "coarse_box.msh"))
@@ -219,6 +241,7 @@ def main():
     rhs4_case("box2x2_N8", box, 8)
     rhsC_case("coarse_box_N3", coarse, 3)
     rhsC_case("box6x5_shuffled_N6", shuffled, 6)
+    advec1d_case()
 
 
 if __name__ == "__main__":

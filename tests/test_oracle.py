@@ -262,3 +262,26 @@ def test_variant_c_numpy_oracle_reproduces_the_reference_script_function(case):
     r = sw2d_rhs_c(d["h"], d["hu"], d["hv"], d["hN"], float(d["g"]), float(d["f"]), d)
     for i in range(4):
         assert np.array_equal(r[i], d[f"rhs{i + 1}"])
+
+
+def test_advec1d_rhs_matches_the_reference_script_function():
+    """BASELINE config 1 (advec1d, N=4, K=100): the host advec1d::computeRHS (C++ and its Python twin
+    pyblitzdg.advec1dComputeRHS) and the C oracle against the output of advec1dComputeRHS of the reference's
+    advec1d.py script (tests/golden/advec1d_rhs_N4_K100.npz)."""
+    import os
+
+    import blitzdg_amd.pyblitzdg as dg
+    from conftest import GOLDEN
+    from oracle import advec1d_rhs
+    d = np.load(os.path.join(GOLDEN, "advec1d_rhs_N4_K100.npz"))
+    nodes = dg.Nodes1DProvisioner(int(d["order"]), int(d["K"]), float(d["xmin"]), float(d["xmax"]))
+    nodes.buildNodes()
+    nodes.computeJacobian()
+    assert np.array_equal(nodes.vmapM, d["vmapM"]) and np.array_equal(nodes.vmapP, d["vmapP"])
+    for u, ref in ((d["u1"], d["rhs1"]), (d["u2"], d["rhs2"])):
+        scale = np.abs(ref).max()
+        got = dg.advec1dComputeRHS(u, float(d["c"]), nodes)
+        assert np.abs(got - ref).max() / scale < 1e-13
+        orc = advec1d_rhs(d["Dr"], d["Lift"], d["rx"], d["Fscale"], d["nx"], d["vmapM"], d["vmapP"], int(d["mapI"]),
+                          int(d["mapO"]), float(d["c"]), u)
+        assert np.abs(orc - ref).max() / scale < 1e-13
