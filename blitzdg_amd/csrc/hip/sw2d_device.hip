@@ -249,6 +249,8 @@ struct bdg_sw2d {
     DevBuf<double> ageo, opsAffine, opsAffineFiltered; // affine-geometry fast path
     DevBuf<double> opsMfma, opsMfmaFiltered;           // same operators in MFMA A-operand layout
     DevBuf<double> opsMfma2, opsMfma2Filtered;         // ... with the lift tiles padded per face
+    DevBuf<double> opsMfma2Src, opsMfma2SrcFiltered;   // ... followed by the source-term tiles F' (variants C/D, N >= 6)
+    bool mfmaSources = false;
     bool affine = false;
     // variant D (reference swhelpers/rhs.py:178-311): optional tracer field and source terms
     int nf = 3;
@@ -388,6 +390,20 @@ struct bdg_sw2d {
             if (nf == 4) { // the tracer has no sources: pre-filtered operators as in variant A
                 p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
                 hipCheck(kt->stageTracer(mode, p, st), what);
+            }
+        } else if (variantD && mfmaSources) {
+            // N >= 6: three conserved fields with sources on the matrix cores, then the tracer pass
+            bdg_dev::PhysParams ph{};
+            if (vd.sources) {
+                ph.sx = vd.zx; ph.sy = vd.zy; ph.fcor = vd.fcor;
+                ph.fconst = vd.fconst; ph.cd = vd.cd;
+                ph.slope = -1.0; ph.dragSign = 1.0;   // swhelpers/rhs.py:300-309
+            }
+            p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
+            hipCheck(kt->stageMfma2Src(mode, p, ph, 0, st), what);
+            if (nf == 4) {
+                p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 1, st), what);
             }
         } else if (variantD) {
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
@@ -905,6 +921,36 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
             const std::vector<double> img2 = mfma2Image(d.Dr, d.Ds, d.Lift);
             s->opsMfma2.alloc(img2.size(), s->bytes);
             hipCheck(hipMemcpy(s->opsMfma2.p, img2.data(), img2.size() * sizeof(double), hipMemcpyHostToDevice), "mfma2 ops upload");
+        }
+        // variants C/D above the unrolled kernels' range: the same image followed by MT*KV tiles of F'
+        // (identity, or Filter for the filtered RHS) through which the sources enter
+        if (s->variantD && s->N > 5) {
+            auto withSourceTiles = [&](std::vector<double> img, const double* F) {
+                const int MT = kt->mfmaMT, KV = kt->mfmaKV;
+                const size_t off = img.size();
+                img.resize(off + static_cast<size_t>(MT) * KV * 64, 0.0);
+                for (int r = 0; r < MT; ++r)
+                    for (int t = 0; t < KV; ++t)
+                        for (int l = 0; l < 64; ++l) {
+                            const int i = 16 * r + (l & 15), k = 4 * t + (l >> 4);
+                            if (i < Np && k < Np)
+                                img[off + (static_cast<size_t>(r) * KV + t) * 64 + l] = F ? F[i * Np + k] : (i == k ? 1.0 : 0.0);
+                        }
+                return img;
+            };
+            const std::vector<double> plainSrc = withSourceTiles(mfma2Image(d.Dr, d.Ds, d.Lift), nullptr);
+            s->opsMfma2Src.alloc(plainSrc.size(), s->bytes);
+            hipCheck(hipMemcpy(s->opsMfma2Src.p, plainSrc.data(), plainSrc.size() * sizeof(double), hipMemcpyHostToDevice),
+                     "mfma2 source ops upload");
+            if (d.Filter) {
+                const std::vector<double> FDr = matmulHost(d.Filter, d.Dr, Np, Np), FDs = matmulHost(d.Filter, d.Ds, Np, Np),
+                                          FL = matmulHost(d.Filter, d.Lift, Np, NFN);
+                const std::vector<double> filtSrc = withSourceTiles(mfma2Image(FDr.data(), FDs.data(), FL.data()), d.Filter);
+                s->opsMfma2SrcFiltered.alloc(filtSrc.size(), s->bytes);
+                hipCheck(hipMemcpy(s->opsMfma2SrcFiltered.p, filtSrc.data(), filtSrc.size() * sizeof(double),
+                                   hipMemcpyHostToDevice), "filtered mfma2 source ops upload");
+            }
+            s->mfmaSources = !std::getenv("BDG_SW2D_ROLLED_SOURCES");
         }
         {
             const std::vector<double> img = mfmaImage(d.Dr, d.Ds, d.Lift);

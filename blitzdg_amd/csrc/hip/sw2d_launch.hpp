@@ -23,6 +23,9 @@ struct KernelTable {
     hipError_t (*stageMfma)(int mode, const StageParams& p, hipStream_t stream);
     int mfma2OpsDoubles, mfma2KF; // face-by-face schedule (lift tiles padded per face)
     hipError_t (*stageMfma2)(int mode, const StageParams& p, hipStream_t stream);
+    // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'), or with tracer != 0
+    // the tracer-equation pass (plain MfmaOps2 image)
+    hipError_t (*stageMfma2Src)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);

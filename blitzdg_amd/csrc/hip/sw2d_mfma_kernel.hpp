@@ -245,14 +245,20 @@ struct MfmaOps2 {
     static constexpr int DOUBLES = OFF_LIFT + MT * 3 * KF * 64;
 };
 
-template <int N, int MODE>
-__global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(const StageParams p) {
+// PHYS = 1: momentum sources of variants C/D (PhysParams, sw2d_affine_kernel.hpp) through the matrix cores as
+// well: the operator image carries one more block of tiles, F' = Filter for the filtered RHS (the drivers
+// filter the whole RHS, sources included) or the identity, and R_c += F' S_c joins the volume term's k-steps,
+// where the lane already holds h, hu, hv of the node it needs.
+template <int N, int MODE, int PHYS = 0>
+__global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(const StageParams p, const PhysParams ph) {
     using E = Elem<N>;
     using O = MfmaOps2<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
+    constexpr int OFF_F = O::DOUBLES;                                  // [r][t][64] tiles of F'
+    constexpr int IMAGE = O::DOUBLES + (PHYS != 0 ? MT * KV * 64 : 0);
 
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    for (int t = threadIdx.x; t < IMAGE; t += blockDim.x) sOps[t] = p.opsAffine[t];
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
@@ -299,15 +305,22 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                          sy = ld_row(ag + 3 * ld, k8);
             constexpr int VC = 3, NC = (KV + VC - 1) / VC;
             double hb[2][VC], hub[2][VC], hvb[2][VC];
+            double sxb[2][PHYS != 0 ? VC : 1], syb[2][PHYS != 0 ? VC : 1], fcb[2][PHYS != 0 ? VC : 1];
             auto loadChunk = [&](int ch, int buf) {
 #pragma unroll
                 for (int s = 0; s < VC; ++s) {
                     const int t = ch * VC + s, m = 4 * t + static_cast<int>(q);
                     hb[buf][s] = 1.0; hub[buf][s] = 0.0; hvb[buf][s] = 0.0;
+                    if constexpr (PHYS != 0) { sxb[buf][s] = 0.0; syb[buf][s] = 0.0; fcb[buf][s] = ph.fconst; }
                     if (t < KV && m < Np) {
                         hb[buf][s] = ld_row(qin + m * ld, k8);
                         hub[buf][s] = ld_row(qin + plane + m * ld, k8);
                         hvb[buf][s] = ld_row(qin + 2 * plane + m * ld, k8);
+                        if constexpr (PHYS != 0) {
+                            if (ph.sx) sxb[buf][s] = ld_row(ph.sx + m * ld, k8);
+                            if (ph.sy) syb[buf][s] = ld_row(ph.sy + m * ld, k8);
+                            if (ph.fcor) fcb[buf][s] = ld_row(ph.fcor + m * ld, k8);
+                        }
                     }
                 }
             };
@@ -331,6 +344,17 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                         const double a1 = w * (rx * hu + ry * hv), b1 = w * (sx * hu + sy * hv);
                         const double a2 = w * (rx * F2 + ry * G2), b2 = w * (sx * F2 + sy * G2);
                         const double a3 = w * (rx * G2 + ry * G3), b3 = w * (sx * G2 + sy * G3);
+                        if constexpr (PHYS != 0) {
+                            const double cdn = ph.cd * fast_sqrt(u * u + v * v), gh = ph.slope * g * h;
+                            const double s2 = -w * fma(gh, sxb[cur][s], fma(fcb[cur][s], hv, -(cdn * u)));
+                            const double s3 = -w * fma(gh, syb[cur][s], fma(ph.dragSign * cdn, v, -(fcb[cur][s] * hu)));
+#pragma unroll
+                            for (int r2 = 0; r2 < MT; ++r2) {
+                                const double Af = sOps[OFF_F + (r2 * KV + t) * 64 + lane];
+                                acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af, s2, acc[1][r2], 0, 0, 0);
+                                acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af, s3, acc[2][r2], 0, 0, 0);
+                            }
+                        }
 #pragma unroll
                         for (int r2 = 0; r2 < MT; ++r2) {
                             const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
@@ -445,6 +469,184 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The passive tracer (field 3 of a four-field state; swhelpers/flux.py:17-19) on the matrix cores, as its own
+// pass after the three-field kernel above, with the same tile / lane layout and operator image (MfmaOps2,
+// plain or pre-filtered: the tracer has no sources): F4 = hN u, G4 = hN v, Lax-Friedrichs with the flow's
+// wave speed. MT accumulator tiles only, so the register budget allows three waves per SIMD.
+template <int N, int MODE>
+__global__ __launch_bounds__(256, 3) void sw2d_stage_mfma2_tracer_kernel(const StageParams p) {
+    using E = Elem<N>;
+    using O = MfmaOps2<N>;
+    constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
+
+    extern __shared__ double sOps[];
+    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const unsigned blk = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const unsigned wave = blk * 4u + (threadIdx.x >> 6), nwaves = nwg * 4u;
+    const unsigned ntiles = (static_cast<unsigned>(p.kend - p.kbegin) + 15u) / 16u;
+    const unsigned perWave = (ntiles + nwaves - 1u) / nwaves;
+    const unsigned tileEnd = min(ntiles, (wave + 1u) * perWave);
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, fo = 3 * plane;
+    const double* __restrict__ qin = p.qin;
+    const double* __restrict__ ag = p.ageo;
+    const double g = p.g;
+    const unsigned kLast = static_cast<unsigned>(p.kend) - 1u;
+
+#pragma unroll 1
+    for (unsigned tile = wave * perWave; tile < tileEnd; ++tile) {
+        const unsigned kTrue = static_cast<unsigned>(p.kbegin) + tile * 16u + j;
+        const bool live = kTrue <= kLast;
+        const unsigned k = live ? kTrue : kLast;
+        const unsigned k8 = k * 8u, k4 = k * 4u;
+
+        mfma_acc_t acc[MT];
+#pragma unroll
+        for (int r = 0; r < MT; ++r) acc[r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+        int fidx[3][KF];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const int n = 4 * tf + static_cast<int>(q);
+                fidx[f][tf] = n < Nfp ? ld_row(p.vmapP + (f * Nfp + n) * ld, k4) : 0;
+            }
+
+        // ---- volume term
+        {
+            const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
+                         sy = ld_row(ag + 3 * ld, k8);
+            constexpr int VC = 3, NC = (KV + VC - 1) / VC;
+            double hb[2][VC], hub[2][VC], hvb[2][VC], hnb[2][VC];
+            auto loadChunk = [&](int ch, int buf) {
+#pragma unroll
+                for (int s = 0; s < VC; ++s) {
+                    const int t = ch * VC + s, m = 4 * t + static_cast<int>(q);
+                    hb[buf][s] = 1.0; hub[buf][s] = 0.0; hvb[buf][s] = 0.0; hnb[buf][s] = 0.0;
+                    if (t < KV && m < Np) {
+                        hb[buf][s] = ld_row(qin + m * ld, k8);
+                        hub[buf][s] = ld_row(qin + plane + m * ld, k8);
+                        hvb[buf][s] = ld_row(qin + 2 * plane + m * ld, k8);
+                        hnb[buf][s] = ld_row(qin + fo + m * ld, k8);
+                    }
+                }
+            };
+            loadChunk(0, 0);
+#pragma unroll
+            for (int ch = 0; ch < NC; ++ch) {
+                const int cur = ch & 1;
+                if (ch + 1 < NC) loadChunk(ch + 1, cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < VC; ++s) {
+                    const int t = ch * VC + s;
+                    if (t < KV) {
+                        const int m = 4 * t + static_cast<int>(q);
+                        const double r = fast_rcp(hb[cur][s]);
+                        const double F4 = hnb[cur][s] * (hub[cur][s] * r), G4 = hnb[cur][s] * (hvb[cur][s] * r);
+                        const double w = m < Np ? -1.0 : 0.0;
+                        const double a = w * (rx * F4 + ry * G4), b = w * (sx * F4 + sy * G4);
+#pragma unroll
+                        for (int r2 = 0; r2 < MT; ++r2) {
+                            acc[r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane], a, acc[r2], 0, 0, 0);
+                            acc[r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane], b, acc[r2], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- surface term
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const double nxf = ld_row(ag + (4 + f) * ld, k8), nyf = ld_row(ag + (7 + f) * ld, k8);
+            const double hfs = 0.5 * ld_row(ag + (10 + f) * ld, k8);
+            double e[KF], d[KF];
+            double lam = 0.0;
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const int n = 4 * tf + static_cast<int>(q);
+                e[tf] = d[tf] = 0.0;
+                if (n < Nfp) {
+                    const int m = fmask_rt<N>(f, n);
+                    const int id = fidx[f][tf];
+                    const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
+                                 hvM = ld_row(qin + 2 * plane + m * ld, k8), nM = ld_row(qin + fo + m * ld, k8);
+                    const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
+                    const double hq = ld_row(qin, o8), nP = ld_row(qin + fo, o8);
+                    double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
+                    if (id < 0) { // reflective wall (the tracer trace is the element's own)
+                        const double un = huM * nxf + hvM * nyf;
+                        huq = huM - 2 * nxf * un;
+                        hvq = hvM - 2 * nyf * un;
+                    }
+                    const double rM = fast_rcp(hM), rP = fast_rcp(hq);
+                    const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
+                    const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                    const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                    lam = fmax(lam, fmax(spdM, spdP));
+                    d[tf] = nM - nP;
+                    e[tf] = (nM * uM - nP * uP) * nxf + (nM * vM - nP * vP) * nyf;
+                }
+            }
+            lam = fmax(lam, __shfl_xor(lam, 16));
+            lam = fmax(lam, __shfl_xor(lam, 32));
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const double s4 = hfs * (e[tf] - lam * d[tf]);
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane], s4, acc[r], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- stage update / output of the tracer field
+        if (live) {
+            double oldv[MT][4], qv[MT][4];
+            if constexpr (MODE != MODE_RHS) {
+                const double* __restrict__ base2 = ((MODE == MODE_LSERK) ? p.res : p.qbase) + fo;
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = 16 * r + static_cast<int>(q) + 4 * reg;
+                        if (i < Np) {
+                            qv[r][reg] = ld_row(qin + fo + i * ld, k8);
+                            oldv[r][reg] = ld_row(base2 + i * ld, k8);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < MT; ++r)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int i = 16 * r + static_cast<int>(q) + 4 * reg;
+                    if (i < Np) {
+                        const double R = acc[r][reg];
+                        if constexpr (MODE == MODE_RHS) {
+                            st_row(p.rhs + fo + i * ld, k8, R);
+                        } else if constexpr (MODE == MODE_LSERK) {
+                            const double n1 = p.ca * oldv[r][reg] + p.cc * R;
+                            st_row(p.res + fo + i * ld, k8, n1);
+                            st_row(p.qout + fo + i * ld, k8, qv[r][reg] + p.cb * n1);
+                        } else {
+                            st_row(p.qout + fo + i * ld, k8, p.ca * oldv[r][reg] + p.cb * qv[r][reg] + p.cc * R);
+                        }
+                    }
+                }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }

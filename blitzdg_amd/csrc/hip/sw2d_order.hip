@@ -184,8 +184,36 @@ hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(BDG_MFMA2_WAVES, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
-    hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
+    hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p, PhysParams{});
     return hipGetLastError();
+}
+
+// matrix-core kernel with the momentum sources (operator image: MfmaOps2 + MT*KV tiles of F'); tracer = 1
+// launches the tracer pass instead (plain MfmaOps2 image). Orders above the unrolled kernels' range only.
+template <int MODE>
+hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
+    if constexpr (!kNoUnrolledSources) return hipErrorNotSupported;
+    else {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    using O = MfmaOps2<kN>;
+    const size_t ldsBytes = sizeof(double) * (O::DOUBLES + (tracer ? 0 : O::MT * O::KV * 64));
+    const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
+    const unsigned waves = tracer ? 3u : static_cast<unsigned>(BDG_MFMA2_WAVES);
+    const unsigned perCu = static_cast<unsigned>(std::min<size_t>(waves, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
+    const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
+    if (tracer) hipLaunchKernelGGL((sw2d_stage_mfma2_tracer_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
+    else hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE, 1>), dim3(grid), dim3(256), ldsBytes, stream, p, ph);
+    return hipGetLastError();
+    }
+}
+
+hipError_t stageMfma2Src(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchMfma2Src<MODE_RHS>(p, ph, tracer, stream);
+    case MODE_LSERK: return launchMfma2Src<MODE_LSERK>(p, ph, tracer, stream);
+    case MODE_COMBINE: return launchMfma2Src<MODE_COMBINE>(p, ph, tracer, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 hipError_t stageMfma2(int mode, const StageParams& p, hipStream_t stream) {
@@ -276,7 +304,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
+                                      &stageMfma2, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

@@ -411,15 +411,21 @@ def test_variant_d_matches_the_reference_function_output(case):
         assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < RHS_TOL, f"RHS{i + 1}"
 
 
-def test_variant_d_filtered_rhs_and_lserk4_vs_numpy_oracle():
+@pytest.mark.parametrize("case,rolled", [("coarse_box_N2", False), ("coarse_box_N4", False), ("coarse_box_N4", True),
+                                         ("coarse_box_N6", False), ("coarse_box_N6", True), ("box2x2_N8", False)])
+def test_variant_d_filtered_rhs_and_lserk4_vs_numpy_oracle(case, rolled, monkeypatch):
     """Filtered four-field RHS (the reference drivers filter sources too, sw2d.py:222-225) and a few
-    fused LSERK4 stages against the NumPy oracle; scalar Coriolis parameter this time."""
+    fused LSERK4 stages against the NumPy oracle; scalar Coriolis parameter this time. Every kernel family:
+    unrolled + tracer pass (N <= 5), matrix cores + tracer pass (N >= 6), and the rolled one-field-per-wave
+    kernel both fall back to (BDG_SW2D_ROLLED_SOURCES=1)."""
     from oracle import lserk4_coefficients
     from oracle.oracle_np import sw2d_rhs4
-    d = _load4("coarse_box_N4")
+    if rolled:
+        monkeypatch.setenv("BDG_SW2D_ROLLED_SOURCES", "1")
+    d = _load4(case)
     t = {k: d[k] for k in ("Dr", "Ds", "Lift", "Filter", "rx", "sx", "ry", "sy", "nx", "ny", "Fscale", "vmapM", "vmapP",
                            "mapW")}
-    t["order"] = 4
+    t["order"] = int(d["order"])
     g, CD, f0 = float(d["g"]), float(d["CD"]), 0.07
     s = sw2d.Sw2dSolver(tables=t, g=g, fields=4, sources={"zx": d["zx"], "zy": d["zy"], "f": f0, "CD": CD})
     q = [d["h"], d["hu"], d["hv"], d["hN"]]
