@@ -84,6 +84,13 @@ struct PhysParams {
     const double* fcor;  // (Np, ld) Coriolis parameter or nullptr -> fconst
     const double* fmat;  // [m][i] = F[i][m] or nullptr
     double fconst, cd, slope, dragSign;
+    // variant B on the matrix-core kernel (PHYS = 2 there): depth planes, open-boundary bit masks, the global
+    // Lax-Friedrichs speed (device scalar), the tide elevation of this evaluation, the sponge field
+    const double* H;
+    const int* obc;
+    const double* lam;
+    const double* spongeField;
+    double tide;
 };
 
 template <int N, int MODE, int PHYS = 0>

@@ -370,6 +370,16 @@ struct bdg_sw2d {
                     lamSlot = nxt;
                 }
                 hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, reuse ? 2 : 1, filter ? filterT.p : nullptr, st), what);
+            } else if (mfmaSources) {
+                // N >= 6: speed pass, then the matrix-core kernel with variant B's surface term and sources
+                vb.lam = lamBuf.p;
+                hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 4, nullptr, st), what);
+                bdg_dev::PhysParams ph{};
+                ph.sx = vb.Hx; ph.sy = vb.Hy; ph.fconst = vb.fcor; ph.cd = vb.cd;
+                ph.slope = 1.0; ph.dragSign = -1.0;             // src/sw2d/main.cpp:461-478
+                ph.H = vb.H; ph.obc = vb.obc; ph.lam = lamBuf.p; ph.spongeField = vb.sponge; ph.tide = vb.tide;
+                p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 2, st), what);
             } else {
                 p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
                 hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 0, nullptr, st), what);
@@ -615,6 +625,51 @@ struct bdg_sw2d {
             opsVdFiltered.alloc(filt.size(), bytes);
             hipCheck(hipMemcpy(opsVdFiltered.p, filt.data(), filt.size() * sizeof(double), hipMemcpyHostToDevice),
                      "filtered source ops upload");
+        }
+    }
+
+    // Operator image of the matrix-core kernel with source terms (variants B/C/D at N >= 6): MfmaOps2 layout --
+    // Dr tiles [r][t], Ds tiles, lift tiles [r][f][tf] -- followed by MT*KV tiles of F' (identity, or Filter with
+    // the other operators pre-multiplied by it). Lane l of a tile holds A[16r + (l&15)][4t + (l>>4)].
+    void buildMfma2SourceOps() {
+        if (opsMfma2Src.p) return;
+        const int MT = kt->mfmaMT, KV = kt->mfmaKV, KF = kt->mfma2KF;
+        auto image = [&](const double* Dr, const double* Ds, const double* Lift, const double* F) {
+            const size_t tilesD = static_cast<size_t>(MT) * KV * 64, offF = static_cast<size_t>(kt->mfma2OpsDoubles);
+            std::vector<double> img(offF + tilesD, 0.0);
+            for (int r = 0; r < MT; ++r)
+                for (int l = 0; l < 64; ++l) {
+                    const int i = 16 * r + (l & 15);
+                    if (i >= Np) continue;
+                    for (int t = 0; t < KV; ++t) {
+                        const int k = 4 * t + (l >> 4);
+                        if (k >= Np) continue;
+                        const size_t at = (static_cast<size_t>(r) * KV + t) * 64 + l;
+                        img[at] = Dr[i * Np + k];
+                        img[tilesD + at] = Ds[i * Np + k];
+                        img[offF + at] = F ? F[i * Np + k] : (i == k ? 1.0 : 0.0);
+                    }
+                    for (int f = 0; f < 3; ++f)
+                        for (int tf = 0; tf < KF; ++tf) {
+                            const int n = 4 * tf + (l >> 4);
+                            if (n < Nfp)
+                                img[2 * tilesD + ((static_cast<size_t>(r) * 3 + f) * KF + tf) * 64 + l] = Lift[i * NFN + f * Nfp + n];
+                        }
+                }
+            return img;
+        };
+        const std::vector<double> plain = image(hostDr.data(), hostDs.data(), hostLift.data(), nullptr);
+        opsMfma2Src.alloc(plain.size(), bytes);
+        hipCheck(hipMemcpy(opsMfma2Src.p, plain.data(), plain.size() * sizeof(double), hipMemcpyHostToDevice),
+                 "mfma2 source ops upload");
+        if (!hostFilter.empty()) {
+            const std::vector<double> FDr = matmulHost(hostFilter.data(), hostDr.data(), Np, Np),
+                                      FDs = matmulHost(hostFilter.data(), hostDs.data(), Np, Np),
+                                      FL = matmulHost(hostFilter.data(), hostLift.data(), Np, NFN);
+            const std::vector<double> filt = image(FDr.data(), FDs.data(), FL.data(), hostFilter.data());
+            opsMfma2SrcFiltered.alloc(filt.size(), bytes);
+            hipCheck(hipMemcpy(opsMfma2SrcFiltered.p, filt.data(), filt.size() * sizeof(double), hipMemcpyHostToDevice),
+                     "filtered mfma2 source ops upload");
         }
     }
 
@@ -922,36 +977,6 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
             s->opsMfma2.alloc(img2.size(), s->bytes);
             hipCheck(hipMemcpy(s->opsMfma2.p, img2.data(), img2.size() * sizeof(double), hipMemcpyHostToDevice), "mfma2 ops upload");
         }
-        // variants C/D above the unrolled kernels' range: the same image followed by MT*KV tiles of F'
-        // (identity, or Filter for the filtered RHS) through which the sources enter
-        if (s->variantD && s->N > 5) {
-            auto withSourceTiles = [&](std::vector<double> img, const double* F) {
-                const int MT = kt->mfmaMT, KV = kt->mfmaKV;
-                const size_t off = img.size();
-                img.resize(off + static_cast<size_t>(MT) * KV * 64, 0.0);
-                for (int r = 0; r < MT; ++r)
-                    for (int t = 0; t < KV; ++t)
-                        for (int l = 0; l < 64; ++l) {
-                            const int i = 16 * r + (l & 15), k = 4 * t + (l >> 4);
-                            if (i < Np && k < Np)
-                                img[off + (static_cast<size_t>(r) * KV + t) * 64 + l] = F ? F[i * Np + k] : (i == k ? 1.0 : 0.0);
-                        }
-                return img;
-            };
-            const std::vector<double> plainSrc = withSourceTiles(mfma2Image(d.Dr, d.Ds, d.Lift), nullptr);
-            s->opsMfma2Src.alloc(plainSrc.size(), s->bytes);
-            hipCheck(hipMemcpy(s->opsMfma2Src.p, plainSrc.data(), plainSrc.size() * sizeof(double), hipMemcpyHostToDevice),
-                     "mfma2 source ops upload");
-            if (d.Filter) {
-                const std::vector<double> FDr = matmulHost(d.Filter, d.Dr, Np, Np), FDs = matmulHost(d.Filter, d.Ds, Np, Np),
-                                          FL = matmulHost(d.Filter, d.Lift, Np, NFN);
-                const std::vector<double> filtSrc = withSourceTiles(mfma2Image(FDr.data(), FDs.data(), FL.data()), d.Filter);
-                s->opsMfma2SrcFiltered.alloc(filtSrc.size(), s->bytes);
-                hipCheck(hipMemcpy(s->opsMfma2SrcFiltered.p, filtSrc.data(), filtSrc.size() * sizeof(double),
-                                   hipMemcpyHostToDevice), "filtered mfma2 source ops upload");
-            }
-            s->mfmaSources = !std::getenv("BDG_SW2D_ROLLED_SOURCES");
-        }
         {
             const std::vector<double> img = mfmaImage(d.Dr, d.Ds, d.Lift);
             s->opsMfma.alloc(img.size(), s->bytes);
@@ -987,6 +1012,10 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     if (d.Filter) s->hostFilter.assign(d.Filter, d.Filter + static_cast<size_t>(Np) * Np);
     if (s->variantD) {
         s->buildSourceOps();
+        if (s->N > 5) {
+            s->buildMfma2SourceOps();
+            s->mfmaSources = !std::getenv("BDG_SW2D_ROLLED_SOURCES");
+        }
         s->vd.nf = s->nf;
         s->vd.sources = d.sources ? 1 : 0;
         s->vd.fconst = d.coriolis_const;
@@ -1170,6 +1199,10 @@ int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* d) {
         s->use();
         s->buildSourceOps();
         s->fastSources = s->N <= 5 && !std::getenv("BDG_SW2D_ROLLED_SOURCES");
+        if (s->N > 5 && !std::getenv("BDG_SW2D_ROLLED_SOURCES")) {
+            s->buildMfma2SourceOps();
+            s->mfmaSources = true;
+        }
         if (s->fastSources && !s->hostFilter.empty() && !s->filterT.p) {
             const int Np = s->Np;
             std::vector<double> ft(static_cast<size_t>(Np) * Np);

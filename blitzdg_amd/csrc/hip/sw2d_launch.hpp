@@ -23,8 +23,8 @@ struct KernelTable {
     hipError_t (*stageMfma)(int mode, const StageParams& p, hipStream_t stream);
     int mfma2OpsDoubles, mfma2KF; // face-by-face schedule (lift tiles padded per face)
     hipError_t (*stageMfma2)(int mode, const StageParams& p, hipStream_t stream);
-    // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'), or with tracer != 0
-    // the tracer-equation pass (plain MfmaOps2 image)
+    // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the
+    // tracer-equation pass (plain MfmaOps2 image); tracer = 2: variant B (image as for the sources)
     hipError_t (*stageMfma2Src)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
@@ -36,7 +36,8 @@ struct KernelTable {
     // variant B (depth, star states, open boundary, global Lax-Friedrichs speed, sources): speed pass over
     // [kbegin, kend) into partials (one double per 256 elements) and *lam, then the fused stage pass
     // unrolled != 0 (N <= 5): the unrolled stage kernel with plain AffineOps in p.opsAffine and the filter
-    // (filterT, [m][i] = F[i][m], or nullptr) applied at the end; otherwise the rolled kernel with a VdOps image
+    // (filterT, [m][i] = F[i][m], or nullptr) applied at the end; 2: the same without the speed pass (vp.lam is
+    // current); 4: speed pass only; 0: speed pass + rolled kernel with a VdOps image
     hipError_t (*stageVb)(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam,
                           int unrolled, const double* filterT, hipStream_t stream);
     // per-block partial maxima (2 doubles per block of 256 elements)

@@ -299,6 +299,13 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                 fidx[f][tf] = n < Nfp ? ld_row(p.vmapP + (f * Nfp + n) * ld, k4) : 0;
             }
 
+        int btags = 0;
+        double lamGlobal = 0.0;
+        if constexpr (PHYS == 2) {
+            btags = ld_row(ph.obc, k4);
+            lamGlobal = *ph.lam;
+        }
+
         // ---- volume term in chunks of VC k-steps, next chunk's loads in flight
         {
             const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
@@ -386,21 +393,44 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                 if (n < Nfp) {
                     const int m = fmask_rt<N>(f, n);
                     const int id = fidx[f][tf];
-                    const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
-                                 hvM = ld_row(qin + 2 * plane + m * ld, k8);
+                    double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
+                           hvM = ld_row(qin + 2 * plane + m * ld, k8);
                     const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
-                    const double hq = ld_row(qin, o8);
+                    double hq = ld_row(qin, o8);
                     double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
-                    if (id < 0) { // reflective wall: no normal flow
-                        const double un = huM * nxf + hvM * nyf;
-                        huq = huM - 2 * nxf * un;
-                        hvq = hvM - 2 * nyf * un;
+                    if constexpr (PHYS == 2) {
+                        const double HM = ld_row(ph.H + m * ld, k8), HP = ld_row(ph.H, o8);
+                        if ((btags >> (f * Nfp + n)) & 1) {   // open boundary (:348-353)
+                            huq = huM;
+                            hvq = hvM;
+                            hq = HM + ph.tide;
+                        } else if (id < 0) {                   // reflective wall (:340-345)
+                            const double un = huM * nxf + hvM * nyf;
+                            hq = hM;
+                            huq = huM - 2 * nxf * un;
+                            hvq = hvM - 2 * nyf * un;
+                        }
+                        const double bM = -HM, bP = -HP, mx = fmax(bP, bM);
+                        const double hMs = fmax(0.0, hM + bM - mx), hPs = fmax(0.0, hq + bP - mx);
+                        const double rMs = fast_rcp(hMs), rPs = fast_rcp(hPs);
+                        huM = hMs * (huM * rMs); hvM = hMs * (hvM * rMs);  // hMstar*(huM/hM), hM = hMstar
+                        huq = hPs * (huq * rPs); hvq = hPs * (hvq * rPs);
+                        hM = hMs;
+                        hq = hPs;
+                    } else {
+                        if (id < 0) { // reflective wall: no normal flow
+                            const double un = huM * nxf + hvM * nyf;
+                            huq = huM - 2 * nxf * un;
+                            hvq = hvM - 2 * nyf * un;
+                        }
                     }
                     const double rM = fast_rcp(hM), rP = fast_rcp(hq);
                     const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
-                    const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
-                    const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
-                    lam = fmax(lam, fmax(spdM, spdP));
+                    if constexpr (PHYS != 2) {
+                        const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                        const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                        lam = fmax(lam, fmax(spdM, spdP));
+                    }
                     const double prM = halfg * hM * hM, prP = halfg * hq * hq;
                     const double F2M = huM * uM + prM, G2M = huM * vM, G3M = hvM * vM + prM;
                     const double F2P = huq * uP + prP, G2P = huq * vP, G3P = hvq * vP + prP;
@@ -410,8 +440,12 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                     e3[tf] = (G2M - G2P) * nxf + (G3M - G3P) * nyf;
                 }
             }
-            lam = fmax(lam, __shfl_xor(lam, 16));
-            lam = fmax(lam, __shfl_xor(lam, 32));
+            if constexpr (PHYS == 2) {
+                lam = lamGlobal;
+            } else {
+                lam = fmax(lam, __shfl_xor(lam, 16));
+                lam = fmax(lam, __shfl_xor(lam, 32));
+            }
 #pragma unroll
             for (int tf = 0; tf < KF; ++tf) {
                 const double s1 = hfs * (e1[tf] - lam * d1[tf]);
@@ -463,7 +497,10 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                                 st_row(p.qout + fo + i * ld, k8, qv[r][reg] + p.cb * n1);
                             } else {
                                 const double val = p.ca * oldv[r][reg] + p.cb * qv[r][reg] + p.cc * R;
-                                st_row(p.qout + fo + i * ld, k8, c == 0 ? val : sponge_relax(val, p.sponge));
+                                double sp = p.sponge;
+                                if constexpr (PHYS == 2)
+                                    if (ph.spongeField) sp = ld_row(ph.spongeField + i * ld, k8);
+                                st_row(p.qout + fo + i * ld, k8, c == 0 ? val : sponge_relax(val, sp));
                             }
                         }
                     }

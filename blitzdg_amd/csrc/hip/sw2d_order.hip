@@ -189,19 +189,21 @@ hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
 }
 
 // matrix-core kernel with the momentum sources (operator image: MfmaOps2 + MT*KV tiles of F'); tracer = 1
-// launches the tracer pass instead (plain MfmaOps2 image). Orders above the unrolled kernels' range only.
+// launches the tracer pass instead (plain MfmaOps2 image), tracer = 2 the variant-B form (same image as the
+// sources). Orders above the unrolled kernels' range only.
 template <int MODE>
 hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
     if constexpr (!kNoUnrolledSources) return hipErrorNotSupported;
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     using O = MfmaOps2<kN>;
-    const size_t ldsBytes = sizeof(double) * (O::DOUBLES + (tracer ? 0 : O::MT * O::KV * 64));
+    const size_t ldsBytes = sizeof(double) * (O::DOUBLES + (tracer == 1 ? 0 : O::MT * O::KV * 64));
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
-    const unsigned waves = tracer ? 3u : static_cast<unsigned>(BDG_MFMA2_WAVES);
+    const unsigned waves = tracer == 1 ? 3u : static_cast<unsigned>(BDG_MFMA2_WAVES);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(waves, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
-    if (tracer) hipLaunchKernelGGL((sw2d_stage_mfma2_tracer_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
+    if (tracer == 1) hipLaunchKernelGGL((sw2d_stage_mfma2_tracer_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
+    else if (tracer == 2) hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE, 2>), dim3(grid), dim3(256), ldsBytes, stream, p, ph);
     else hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE, 1>), dim3(grid), dim3(256), ldsBytes, stream, p, ph);
     return hipGetLastError();
     }
@@ -253,6 +255,7 @@ hipError_t launchVb(const StageParams& p, const VbParams& vp, double* partials, 
         hipLaunchKernelGGL((sw2d_vb_speed_kernel<kN>), dim3(nblocks), dim3(256), 0, stream, p, vp, partials);
         hipLaunchKernelGGL((sw2d_vb_speed_reduce_kernel<kN>), dim3(1), dim3(256), 0, stream, partials, static_cast<int>(nblocks), lam);
     }
+    if (unrolled == 4) return hipGetLastError(); // speed pass only: the stage pass is the matrix-core kernel
     if constexpr (!kNoUnrolledSources) {
         if (unrolled) {
             const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);

@@ -781,3 +781,21 @@ def test_variant_b_lserk4_and_fused_speed_reduction(order, coarse_mesh, monkeypa
     assert abs(t_end - time) < 1e-9 * time
     for a, b in zip(got, q):
         assert relmax(a, b) < STATE_TOL
+
+
+@pytest.mark.parametrize("order", [3, 7])
+def test_variant_b_rolled_kernels_as_cross_check(order, coarse_mesh, monkeypatch):
+    """BDG_SW2D_ROLLED_SOURCES=1 selects the rolled one-field-per-wave form of variant B at every order (the
+    general speed pass + sw2d_stage_vb_kernel): same answers as the default kernel families and the oracle."""
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    nodes, t, e = variant_b_setup(order, coarse_mesh)
+    Hx, Hy = nodes.bedSlopes(e["H"])
+    ref = onp.sw2d_rhs_b(e["h"], e["hu"], e["hv"], e["H"], Hx, Hy, 9.81, e["f"], e["CD"], e["time"], t, e["mapO"])
+    scale = max(np.abs(x).max() for x in ref)
+    fast = _variant_b_solver(nodes, e, Hx, Hy).computeRHS(e["h"], e["hu"], e["hv"], filter=True)
+    monkeypatch.setenv("BDG_SW2D_ROLLED_SOURCES", "1")
+    rolled = _variant_b_solver(nodes, e, Hx, Hy).computeRHS(e["h"], e["hu"], e["hv"], filter=True)
+    for a, b, c in zip(fast, rolled, ref):
+        assert np.abs(a - t["Filter"] @ c).max() / scale < RHS_TOL
+        assert np.abs(b - t["Filter"] @ c).max() / scale < RHS_TOL
