@@ -799,3 +799,27 @@ def test_variant_b_rolled_kernels_as_cross_check(order, coarse_mesh, monkeypatch
     for a, b, c in zip(fast, rolled, ref):
         assert np.abs(a - t["Filter"] @ c).max() / scale < RHS_TOL
         assert np.abs(b - t["Filter"] @ c).max() / scale < RHS_TOL
+
+
+@pytest.mark.parametrize("order", [1, 4, 8])
+def test_smallest_mesh_two_triangles(order):
+    """One cell = two triangles: every face but the diagonal is a wall, every launch is a partial wavefront /
+    a partial 16-element tile."""
+    m = dg.MeshManager()
+    m.buildBoxMesh(1, 1)
+    nodes = dg.TriangleNodesProvisioner(order, m)
+    nodes.buildFilter(0.9 * order, order)
+    t = tables_from_nodes(nodes)
+    assert t["rx"].shape[1] == 2
+    h, hu, hv = seeded_fields(t["x"], t["y"], seed=7)
+    o = oracle_from(t)
+    s = sw2d.Sw2dSolver(nodes=nodes)
+    ref = o.rhs(h, hu, hv)
+    scale = max(np.abs(x).max() for x in ref)
+    got = s.computeRHS(h, hu, hv)
+    assert max(np.abs(a - b).max() for a, b in zip(got, ref)) / scale < RHS_TOL
+    dt = 0.5 * o.dt(h, hu, hv, 0.65, order)
+    assert s.setState(h, hu, hv) is None and s.computeDt(0.65)[0] == 2 * dt
+    s.stepRK2(dt, 3, filter=True)
+    for a, b in zip(s.getState(), o.step_rk2(h, hu, hv, dt, 3, filter=True)):
+        assert relmax(a, b) < STATE_TOL
