@@ -431,7 +431,9 @@ struct bdg_sw2d {
             hipCheck(kt->stage(mode, filter, p, st), what);
         }
     }
-    bool fastSources = false; // variant D on the unrolled kernel (N <= 5) instead of the rolled one
+    bool fastSources = false; // variants B/C/D on the unrolled kernels instead of the rolled ones
+    // up to this order the unrolled source-term kernels are used, above it the matrix-core ones
+    static constexpr int kUnrolledSourcesMaxOrder = 4;
     DevBuf<double> filterT;   // [m][i] = Filter[i][m], for filtered source terms
     // :352  hP = HM + amp cos(om t) 1/2 (tanh(ramp (t - T)) + 1)
     double tideAt(double t) const {
@@ -444,8 +446,9 @@ struct bdg_sw2d {
     double lamTideFor = 0.0;
     double nextEvalTime = 0.0;         // model time of the evaluation that will follow the current launch
     // elements below which the matrix-core kernel is the faster one, per order (measured crossovers:
-    // N=2 between 30 k and 61 k, N=3 near 125 k, N=4 between 125 k and 250 k, N=5 near 61 k; N=1 never ahead)
-    static constexpr int kSmallLaunch[6] = {0, 4000, 40000, 100000, 160000, 60000};
+    // N=2 between 30 k and 61 k, N=3 near 125 k, N=4 between 125 k and 250 k; N=1 never ahead; N=5 runs on
+    // the matrix cores at every size)
+    static constexpr int kSmallLaunch[6] = {0, 4000, 40000, 100000, 160000, 0};
     bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
 
     void launchRhs(const double* qin, double* out, bool filter) {
@@ -911,9 +914,10 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->uploadRows(d.Fscale, s->fscaleNodal, NFN);
 
     // ---- affine fast path: one metric value per element, one normal/scale per face
-    // Measured on MI355X: the fully unrolled vector kernel wins up to N=5; from
-    // N=6 on its basic block outgrows the register files and the matrix-core kernel is fastest.
-    s->affineVariant = s->N <= 5 ? 0 : 6;
+    // Measured on MI355X: the fully unrolled vector kernel wins up to N=4; from
+    // N=5 on its basic block outgrows the register files and the matrix-core kernel is fastest
+    // (N=5, 640 k elements: 0.454 ms unrolled, 0.405 ms matrix cores).
+    s->affineVariant = s->N <= 4 ? 0 : 6;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 6) {
@@ -1012,7 +1016,7 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     if (d.Filter) s->hostFilter.assign(d.Filter, d.Filter + static_cast<size_t>(Np) * Np);
     if (s->variantD) {
         s->buildSourceOps();
-        if (s->N > 5) {
+        if (s->N > bdg_sw2d::kUnrolledSourcesMaxOrder) {
             s->buildMfma2SourceOps();
             s->mfmaSources = !std::getenv("BDG_SW2D_ROLLED_SOURCES");
         }
@@ -1034,7 +1038,7 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
         }
         // Measured at C3 (10^6 triangles, N=4): rolled kernel 0.87 ms (3 fields) / 1.16 ms (4 fields) per
         // stage; unrolled kernel + tracer launch: see DESIGN.md section 3.
-        s->fastSources = s->N <= 5 && !std::getenv("BDG_SW2D_ROLLED_SOURCES");
+        s->fastSources = s->N <= bdg_sw2d::kUnrolledSourcesMaxOrder && !std::getenv("BDG_SW2D_ROLLED_SOURCES");
         if (s->fastSources && d.Filter) {
             std::vector<double> ft(static_cast<size_t>(Np) * Np);
             for (int m = 0; m < Np; ++m)
@@ -1198,8 +1202,8 @@ int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* d) {
                 throw arg_error("bdg_sw2d_enable_variant_b: open-boundary node index out of range");
         s->use();
         s->buildSourceOps();
-        s->fastSources = s->N <= 5 && !std::getenv("BDG_SW2D_ROLLED_SOURCES");
-        if (s->N > 5 && !std::getenv("BDG_SW2D_ROLLED_SOURCES")) {
+        s->fastSources = s->N <= bdg_sw2d::kUnrolledSourcesMaxOrder && !std::getenv("BDG_SW2D_ROLLED_SOURCES");
+        if (s->N > bdg_sw2d::kUnrolledSourcesMaxOrder && !std::getenv("BDG_SW2D_ROLLED_SOURCES")) {
             s->buildMfma2SourceOps();
             s->mfmaSources = true;
         }

@@ -13,9 +13,13 @@ constexpr int kN = BDG_ORDER;
 constexpr int kBlock = 256;
 // Orders above this use the field-split kernels only (3*Np accumulators exceed the VGPR file).
 constexpr bool kHighOrder = BDG_ORDER > 6;
-// The unrolled source-term / tracer kernels are the default only up to this order (createSolver:
-// fastSources); above it they are not instantiated (each costs minutes of compile time at N = 6).
-constexpr bool kNoUnrolledSources = BDG_ORDER > 5;
+// The unrolled source-term / tracer / variant-B kernels are the default only up to N = 4 (createSolver:
+// kUnrolledSourcesMaxOrder); above it they are not instantiated (each costs minutes of compile time).
+constexpr bool kNoUnrolledSources = BDG_ORDER > 4;
+// The streamed unrolled A/B variants (BDG_SW2D_AFFINE_VARIANT = 2, 3) exist up to N = 5.
+constexpr bool kNoStream = BDG_ORDER > 5;
+// The matrix-core source-term / tracer / variant-B kernels exist from this order up.
+constexpr bool kMfmaSources = BDG_ORDER >= 5;
 
 // Rolled kernels. FIELDS = 1 (three waves per 64 elements, one field each) exists for every
 // order; FIELDS = 3 (all fields per lane) only where 3*Np accumulators fit (N <= 6).
@@ -117,7 +121,7 @@ hipError_t stageAffineSrc(int mode, const StageParams& p, const PhysParams& ph, 
 
 template <int MODE, int WAVES>
 hipError_t launchStream(const StageParams& p, hipStream_t stream) {
-    if constexpr (kNoUnrolledSources) return stageFieldSplit(MODE, p, stream); // A/B variant, N <= 5 only
+    if constexpr (kNoStream) return stageFieldSplit(MODE, p, stream); // A/B variant, N <= 5 only
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
@@ -193,7 +197,7 @@ hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
 // sources). Orders above the unrolled kernels' range only.
 template <int MODE>
 hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
-    if constexpr (!kNoUnrolledSources) return hipErrorNotSupported;
+    if constexpr (!kMfmaSources) return hipErrorNotSupported;
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     using O = MfmaOps2<kN>;
