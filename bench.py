@@ -105,6 +105,22 @@ def cpu_baseline(order):
             "gbps_algorithmic_single": out["single"] / Np * algorithmic_bytes_per_element(order) / 1e9}
 
 
+def stage_kernel_name(order, elements, affine):
+    """Name of the kernel a default LSERK4 stage launch of this size runs (blitzdg_amd/csrc/hip/sw2d_device.hip:
+    unrolled vector kernel up to N=4 for large launches, matrix cores otherwise)."""
+    if not affine:
+        return f"sw2d_stage_kernel<{order}, MODE_LSERK, false>"
+    forced = os.environ.get("BDG_SW2D_AFFINE_VARIANT")
+    if forced is not None:
+        return f"BDG_SW2D_AFFINE_VARIANT={forced} <{order}, MODE_LSERK>"
+    small = {1: 4000, 2: 40000, 3: 100000, 4: 160000}
+    if order >= 5:
+        return f"sw2d_stage_mfma2_kernel<{order}, MODE_LSERK>"
+    if elements < small[order]:
+        return f"sw2d_stage_mfma_kernel<{order}, MODE_LSERK>"
+    return f"sw2d_stage_affine_kernel<{order}, MODE_LSERK>"
+
+
 def run_single(args):
     os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 8)))
     import blitzdg_amd.pyblitzdg as dg
@@ -159,7 +175,7 @@ def run_single(args):
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": bytes_elem * K, "kernel_ms": ms_per_launch,
                      "measured_stream_triad_GBps": triad, "same_access_pattern_no_compute_ms": probe_ms,
-                     "kernel": ("sw2d_stage_mfma_kernel" if ORDER > 5 else "sw2d_stage_affine_kernel") + f"<{ORDER}, MODE_LSERK>" if solver.usesAffineGeometry else f"sw2d_stage_kernel<{ORDER}, MODE_LSERK, false>"},
+                     "kernel": stage_kernel_name(ORDER, K, solver.usesAffineGeometry)},
     }
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(ORDER)
