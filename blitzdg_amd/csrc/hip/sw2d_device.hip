@@ -1561,9 +1561,8 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         s->commWorld = world;
         s->peers = peers;
         hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
-        // same-device ordering only: no system-scope fence on record (measured: 3 us less per stage)
         for (hipEvent_t* e : {&s->evA[0], &s->evA[1], &s->evB[0], &s->evB[1]})
-            hipCheck(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate");
+            hipCheck(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
         const size_t rows = static_cast<size_t>(s->nf) * s->Np;
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
