@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     // part is a 32-bit offset, so a load needs no 64-bit vector address arithmetic.
     const unsigned k = static_cast<unsigned>(p.kbegin) + tile * blockDim.x + threadIdx.x;
     if (k >= static_cast<unsigned>(p.kend)) return;
-    const unsigned k8 = k * 8u, k4 = k * 4u; // Np*ld*8 < 2^31 is checked on the host
+    const unsigned k8 = k * 8u, k4 = k * 4u; // Np*ld*8 < 2^32 is checked on the host
 
     const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
     const double* __restrict__ ops = p.opsAffine; // wave-uniform reads -> scalar loads

@@ -810,8 +810,10 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->numInterior = s->numOwned = s->K;
     const int Np = s->Np, Nfp = s->Nfp, NFN = s->NFN, K = s->K;
     const long long ld = s->ld;
-    if (static_cast<long long>(Np) * ld > 2147483647LL)
-        throw arg_error("bdg_sw2d_create: Np*K exceeds the 32-bit gather offsets");
+    // Lane addresses are a wave-uniform row pointer plus a 32-bit unsigned BYTE offset (8 * node offset).
+    if (static_cast<long long>(Np) * ld * 8 > 4294967295LL)
+        throw arg_error("bdg_sw2d_create: Np*K exceeds 2^29 nodes (32-bit byte offsets within a field): partition the "
+                        "mesh over more devices");
 
     // ---- validate the index tables on the host before anything touches the GPU
     const size_t nFaceNodes = static_cast<size_t>(NFN) * K;
