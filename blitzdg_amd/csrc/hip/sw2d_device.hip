@@ -1625,6 +1625,14 @@ int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int
                 throw arg_error("bdg_sw2d_group_lserk4_stages: parts differ in order / field count");
         }
         if (num_stages == 0) return;
+        for (int r = 0; r < num_parts; ++r)          // direct access between the GPUs that exchange ghosts
+            for (const bdg_sw2d::Peer& pr : parts[r]->peers)
+                if (parts[pr.rank]->device != parts[r]->device) {
+                    parts[r]->use();
+                    const hipError_t e = hipDeviceEnablePeerAccess(parts[pr.rank]->device, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) hipCheck(e, "hipDeviceEnablePeerAccess");
+                    (void)hipGetLastError();
+                }
         const size_t rows = static_cast<size_t>(parts[0]->nf) * parts[0]->Np;
         for (int r = 0; r < num_parts; ++r) {
             bdg_sw2d* s = parts[r];
@@ -1658,10 +1666,13 @@ int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int
                     for (const bdg_sw2d::Peer& b : src->peers)
                         if (b.rank == r) back = &b;
                     hipCheck(hipStreamWaitEvent(s->commStream, src->evPacked[cur], 0), "hipStreamWaitEvent");
-                    hipCheck(hipMemcpyAsync(s->recvBuf.p + static_cast<size_t>(pr.recvStart) * rows,
-                                            src->sendBuf.p + static_cast<size_t>(back->sendStart) * rows,
-                                            static_cast<size_t>(pr.recvCount) * rows * sizeof(double),
-                                            hipMemcpyDeviceToDevice, s->commStream), "ghost copy");
+                    double* dst = s->recvBuf.p + static_cast<size_t>(pr.recvStart) * rows;
+                    const double* from = src->sendBuf.p + static_cast<size_t>(back->sendStart) * rows;
+                    const size_t bytes = static_cast<size_t>(pr.recvCount) * rows * sizeof(double);
+                    if (src->device == s->device)
+                        hipCheck(hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToDevice, s->commStream), "ghost copy");
+                    else  // another GPU of the node: the copy engine pulls over xGMI
+                        hipCheck(hipMemcpyPeerAsync(dst, s->device, from, src->device, bytes, s->commStream), "ghost peer copy");
                 }
                 hipCheck(hipEventRecord(s->evCopied[cur], s->commStream), "hipEventRecord");
             }
