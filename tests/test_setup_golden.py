@@ -339,3 +339,27 @@ def test_gmsh_write_read_round_trip(tmp_path):
     assert b.numElements == 2400 and b.numVerts == 41 * 31
     for name in ("elements", "vertices", "EToE", "EToF", "bcType"):
         assert np.array_equal(getattr(a, name), getattr(b, name)), name
+
+
+def test_host_setup_code_is_clean_under_address_and_ub_sanitizers(tmp_path):
+    """The host-side setup path (mesh reader / writer, connectivity, partition, provisioners, filter,
+    splitElements, *.vtu writer, advec1d) compiled with -fsanitize=address,undefined and run on the CPU
+    (GPU sanitizers are not available on the pool; the HIP side is covered by the parity tests)."""
+    import glob
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    srcs = [f for f in glob.glob(os.path.join(root, "blitzdg_amd", "csrc", "host", "*.cpp"))
+            if os.path.basename(f) not in ("capi_host.cpp", "sw2d_frontend.cpp")]
+    exe = str(tmp_path / "host_check")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fopenmp",
+           "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "blitzdg_amd", "csrc", "host"),
+           os.path.join(root, "tests", "host_sanitizer_check.cpp"), *srcs, "-o", exe]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([exe, os.path.join(root, "tests", "golden", "coarse_box.msh")], capture_output=True, text=True,
+                         timeout=600, env=dict(os.environ, OMP_NUM_THREADS="4", ASAN_OPTIONS="detect_leaks=1"), cwd=str(tmp_path))
+    assert run.returncode == 0 and "host check ok" in run.stdout, run.stdout[-2000:] + run.stderr[-4000:]
+    assert "runtime error" not in run.stderr and "AddressSanitizer" not in run.stderr
