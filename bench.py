@@ -146,6 +146,15 @@ def run_single(args):
     solver.synchronize()
     wall = time.perf_counter() - t0
     _, eta_max = solver.computeDt(CFL)  # raises if the run blew up
+    # total mass before / after (walls everywhere: conserved to round-off). Computed only now: NumPy's BLAS
+    # threads keep spinning for a while after a product and would compete with the launch thread above.
+    V = ctx.V
+    quad = np.linalg.inv(V @ V.T).sum(axis=0)  # nodal quadrature weights of the reference triangle
+
+    def total_mass(hh):
+        return float((quad @ hh * ctx.J[0]).sum())
+    mass0 = total_mass(h)
+    mass_drift = (total_mass(solver.getState()[0]) - mass0) / mass0
     probe_ms = solver.probeStageTraffic(20) if solver.usesAffineGeometry else None
     triad = sw2d.streamTriadGBps(0)
 
@@ -169,7 +178,8 @@ def run_single(args):
                                if solver.usesAffineGeometry else "nodal",
                    "actual_hbm_bytes_per_element": actual_bytes_per_element(ORDER, solver.usesAffineGeometry),
                    "renumbered_internally": solver.isRenumbered,
-                   "dt": dt, "eta_max_after": eta_max, "setup_seconds": round(t_setup, 2),
+                   "dt": dt, "eta_max_after": eta_max, "mass_relative_drift": mass_drift,
+                   "setup_seconds": round(t_setup, 2),
                    "device_bytes": solver.deviceBytes},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -182,7 +192,7 @@ def run_single(args):
     print(json.dumps(line), flush=True)
 
 
-def distributed_line(world, steps, warmup, wall, K, Np, counts, transport):
+def distributed_line(world, steps, warmup, wall, K, Np, counts, transport, mass_drift=None):
     bytes_elem = algorithmic_bytes_per_element(ORDER)
     achieved = bytes_elem * K * steps / wall / 1e9
     return {
@@ -193,11 +203,13 @@ def distributed_line(world, steps, warmup, wall, K, Np, counts, transport):
         "ms_per_step": wall / steps * 1e3,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "sw2d RHS + fused LSERK4 stage, synthetic box 1000x500 cells = 1e6 "
-                               f"triangles, N=4, partitioned into {world} parts (RCB), ghost-element "
+        "config": {"workload": f"sw2d RHS + fused LSERK4 stage, synthetic box {NX}x{NY} cells = {K} "
+                               f"triangles, N={ORDER}, partitioned into {world} parts (RCB), ghost-element "
                                "halo over RCCL overlapped with interior elements",
                    "order": ORDER, "elements": K, "fields": 3, "parallelism": f"elem-partition x{world}",
-                   "transport": transport, "rank0_partition": counts},
+                   "transport": transport, "rank0_partition": counts,
+                   # walls everywhere: total mass is conserved to round-off only if every ghost trace is right
+                   "mass_relative_drift": mass_drift},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS * world, "unit": "GB/s",
                      "frac": achieved / (HBM_PEAK_GBPS * world), "traffic": None,
                      "note": "whole-job wall time incl. halo exchange, not a per-kernel figure"},
@@ -233,9 +245,13 @@ def run_distributed_native(args):
         d.barrier()
         wall = d.allreduce_max(time.perf_counter() - t0)
         d.compute_dt(CFL)  # blow-up check (global)
+        # mass before / after, only now (NumPy's BLAS threads would disturb the launch thread of the timed loop)
+        mass1 = d.allreduce_sum(d.owned_mass())
+        mass0 = d.allreduce_sum(d.owned_mass(initial_state))
         if rank == 0:
             print(json.dumps(distributed_line(world, args.steps, args.warmup, wall, d.global_elements, d.Np,
-                                              d.halo_counts(), "native RCCL (ncclSend/ncclRecv groups)")), flush=True)
+                                              d.halo_counts(), "native RCCL (ncclSend/ncclRecv groups)",
+                                              mass_drift=(mass1 - mass0) / mass0)), flush=True)
     finally:
         d.close()
 

@@ -152,6 +152,7 @@ _SIGNATURES = {
     "bdg_sw2d_group_lserk4_stages": (c_int, [POINTER(_P), c_int, c_double, c_int]),
     "bdg_sw2d_compute_dt_global": (c_int, [_P, c_double, POINTER(c_double), POINTER(c_double)]),
     "bdg_sw2d_allreduce_max": (c_int, [_P, c_double, POINTER(c_double)]),
+    "bdg_sw2d_allreduce_sum": (c_int, [_P, c_double, POINTER(c_double)]),
     "bdg_sw2d_barrier": (c_int, [_P]),
     "bdg_sw2d_rhs_resident": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_synchronize": (c_int, [_P]),

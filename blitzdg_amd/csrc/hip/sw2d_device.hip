@@ -555,11 +555,11 @@ struct bdg_sw2d {
     }
 
     // max (or min) of one double over all ranks, through the device
-    double allReduceScalar(double v, bool takeMax) {
+    double allReduceScalar(double v, bool takeMax, bool sum = false) {
         if (!comm || commWorld == 1) return v;
         hipCheck(hipMemcpyAsync(scalarBuf.p, &v, sizeof(double), hipMemcpyHostToDevice, stream), "H2D copy");
-        ncclCheck(rccl().AllReduce(scalarBuf.p, scalarBuf.p + 1, 1, ncclDouble, takeMax ? ncclMax : ncclMin, comm, stream),
-                  "ncclAllReduce");
+        ncclCheck(rccl().AllReduce(scalarBuf.p, scalarBuf.p + 1, 1, ncclDouble, sum ? ncclSum : (takeMax ? ncclMax : ncclMin),
+                                   comm, stream), "ncclAllReduce");
         double out = 0.0;
         hipCheck(hipMemcpyAsync(&out, scalarBuf.p + 1, sizeof(double), hipMemcpyDeviceToHost, stream), "D2H copy");
         hipCheck(hipStreamSynchronize(stream), "allreduce sync");
@@ -1728,6 +1728,15 @@ int bdg_sw2d_allreduce_max(bdg_sw2d* s, double value, double* out) {
         if (!out) throw arg_error("bdg_sw2d_allreduce_max: out is NULL");
         s->use();
         *out = s->allReduceScalar(value, true);
+    });
+}
+
+int bdg_sw2d_allreduce_sum(bdg_sw2d* s, double value, double* out) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_allreduce_sum");
+        if (!out) throw arg_error("bdg_sw2d_allreduce_sum: out is NULL");
+        s->use();
+        *out = s->allReduceScalar(value, false, true);
     });
 }
 

@@ -252,8 +252,23 @@ class NativeDistributedSw2d:
         self._check(self._lib.bdg_sw2d_allreduce_max(self.solver._h, float(value), self._byref(out)))
         return out.value
 
+    def allreduce_sum(self, value):
+        out = self._c_double()
+        self._check(self._lib.bdg_sw2d_allreduce_sum(self.solver._h, float(value), self._byref(out)))
+        return out.value
+
     def barrier(self):
         self._check(self._lib.bdg_sw2d_barrier(self.solver._h))
+
+    def owned_mass(self, fn=None):
+        """Integral of h over this rank's owned elements (nodal quadrature with the mass matrix' row sums);
+        of the resident state, or of ``fn(x, y)[0]`` when a state function is given."""
+        ctx = self.nodes.dgContext()
+        V = ctx.V
+        w = np.linalg.inv(V @ V.T).sum(axis=0)
+        n = self.plan.num_owned
+        h = (self.solver.getState()[0] if fn is None else fn(ctx.x, ctx.y)[0])[:, :n]
+        return float((w @ h * ctx.J[0, :n]).sum())
 
     def owned_state(self):
         h, hu, hv = self.solver.getState()

@@ -314,6 +314,7 @@ int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int
 /* bdg_sw2d_compute_dt with the maxima reduced over all ranks (one 8-byte all-reduce each). */
 int bdg_sw2d_compute_dt_global(bdg_sw2d* s, double cfl, double* dt, double* eta_max);
 int bdg_sw2d_allreduce_max(bdg_sw2d* s, double value, double* out);
+int bdg_sw2d_allreduce_sum(bdg_sw2d* s, double value, double* out); /* e.g. total mass over all ranks */
 /* Drains this rank's streams, meets every other rank, drains again. */
 int bdg_sw2d_barrier(bdg_sw2d* s);
 /* RHS of the resident state (owned elements valid; ghosts must be current) to host arrays. */

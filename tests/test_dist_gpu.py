@@ -190,6 +190,7 @@ def test_bench_distributed_entry_point_with_native_rccl_single_rank():
                     "MASTER_PORT": str(_free_port()), "BDG_BENCH_FORCE_DISTRIBUTED": "1"})
     assert d["n_gpus"] == 1 and d["steps"] == 20 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["elements"] == 4800
+    assert abs(d["config"]["mass_relative_drift"]) < 1e-13  # walls everywhere: mass is conserved to round-off
 
 
 def test_bench_loopback_rehearsal_of_an_eight_way_split():
