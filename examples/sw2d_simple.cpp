@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     try {
         MeshManager meshManager;
         if (meshArg.rfind("box:", 0) == 0) {
-            const auto x = meshArg.find('x');
+            const auto x = meshArg.find('x', 4);
             meshManager.buildBoxMesh(std::atoi(meshArg.substr(4, x - 4).c_str()), std::atoi(meshArg.substr(x + 1).c_str()),
                                      -1, 1, -1, 1);
         } else {

@@ -823,3 +823,13 @@ def test_smallest_mesh_two_triangles(order):
     s.stepRK2(dt, 3, filter=True)
     for a, b in zip(s.getState(), o.step_rk2(h, hu, hv, dt, 3, filter=True)):
         assert relmax(a, b) < STATE_TOL
+
+
+def test_cpp_drivers_accept_a_synthetic_box_argument():
+    """`box:NXxNY` instead of a mesh file (the 'x' of 'box' must not be taken for the separator)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for exe, args in (("sw2d-simple", ["box:12x7", "2", "1e9", "5"]), ("sw2d", ["box:12x7", "2", "5", "resident"])):
+        out = subprocess.run([os.path.join(root, "bin", exe), *args], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "steps=5" in out.stdout, out.stdout + out.stderr
