@@ -201,3 +201,89 @@ def test_bench_loopback_rehearsal_of_an_eight_way_split():
     assert d["rehearsal"] and d["world"] == 8 and [r["rank"] for r in d["ranks"]] == [0, 5]
     for r in d["ranks"]:
         assert r["owned"] == 3200 and r["ghost"] > 0 and r["peers"] >= 1 and 0 < r["ms_per_stage"] < 5
+
+
+# ---- the real multi-process path (one process per rank, the library's own communicator and stage loop) with a
+# ---- file-based stand-in for librccl.so, so that the ranks can share the single GPU of a test box
+
+@pytest.fixture(scope="module")
+def mock_rccl(tmp_path_factory):
+    import subprocess
+    out = tmp_path_factory.mktemp("mock_rccl")
+    lib = out / "libmock_rccl.so"
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-fPIC", "-shared", "--offload-arch=gfx950", "-I/opt/rocm/include",
+           os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), "-o", str(lib)]
+    build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    return {"BDG_RCCL_LIBRARY": str(lib), "BDG_MOCK_RCCL_DIR": str(out)}
+
+
+def _native_worker(rank, world, port, env, out_dir):
+    import faulthandler
+    faulthandler.enable()
+    sys.path.insert(0, ROOT)
+    os.environ.update(env)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    from blitzdg_amd.halo import NativeDistributedSw2d
+    d = NativeDistributedSw2d.box(NX, NY, ORDER, rank, world, device=0)
+    try:
+        d.set_initial_state(_fields)
+        dt = 0.5 * d.compute_dt(0.65)          # global minimum through the communicator's all-reduce
+        mass0 = d.allreduce_sum(d.owned_mass())
+        d.lserk4_stages(dt, 3)                 # several calls: the two chains re-join between them
+        d.lserk4_stages(dt, NSTAGES - 3)
+        d.barrier()
+        mass1 = d.allreduce_sum(d.owned_mass())
+        ids, h, hu, hv = d.owned_state()
+        np.savez(os.path.join(out_dir, f"native{rank}.npz"), ids=ids, h=h, hu=hu, hv=hv, dt=dt, mass0=mass0, mass1=mass1,
+                 total=d.global_elements, **d.halo_counts())
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_native_multi_process_path_matches_single_domain(tmp_path, world, mock_rccl):
+    """One process per rank exactly as under torchrun -- file rendezvous of the communicator id,
+    bdg_sw2d_comm_init, the library's two-chain stage loop with grouped send / receive on the exchange
+    stream, all-reduces for dt and mass -- with only librccl.so replaced (tests/mock_rccl). Owned states must
+    equal the single-domain run bit for bit, and total mass must be conserved to round-off."""
+    import torch.multiprocessing as mp
+    mp.start_processes(_native_worker, args=(world, _free_port(), mock_rccl, str(tmp_path)), nprocs=world, join=True,
+                       start_method="spawn")
+    parts = [np.load(tmp_path / f"native{r}.npz") for r in range(world)]
+    dt = float(parts[0]["dt"])
+    assert all(float(p["dt"]) == dt for p in parts)
+    ref = _single_domain(dt)
+    seen = np.zeros(int(parts[0]["total"]), dtype=int)
+    for p in parts:
+        ids = p["ids"]
+        seen[ids] += 1
+        assert int(p["ghost"]) > 0 and int(p["interior"]) < int(p["owned"])
+        for name, full in zip(("h", "hu", "hv"), ref):
+            assert np.array_equal(p[name], full[:, ids]), f"{name} differs on a rank"
+        assert abs(float(p["mass1"]) - float(p["mass0"])) < 1e-13 * abs(float(p["mass0"]))
+    assert (seen == 1).all()
+
+
+def test_bench_two_ranks_through_the_mock_transport(mock_rccl):
+    """bench.py as the driver launches it for N = 2 (two processes, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
+    both on this GPU through the stand-in transport: rank 0 prints the one JSON line, rank 1 nothing."""
+    import json
+    import subprocess
+    port = str(_free_port())
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, **mock_rccl)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "15",
+                                       "--warmup", "5", "--cells", "60x40"], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "".join(o[0][-1500:] + o[1][-1500:] for o in outs)
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines0) == 1 and not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]
+    d = json.loads(lines0[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 15 and d["value"] > 0 and d["scaling"] == "strong"
+    assert d["config"]["rank0_partition"]["ghost"] > 0
+    assert abs(d["config"]["mass_relative_drift"]) < 1e-13
