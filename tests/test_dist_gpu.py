@@ -287,3 +287,22 @@ def test_bench_two_ranks_through_the_mock_transport(mock_rccl):
     assert d["n_gpus"] == 2 and d["steps"] == 15 and d["value"] > 0 and d["scaling"] == "strong"
     assert d["config"]["rank0_partition"]["ghost"] > 0
     assert abs(d["config"]["mass_relative_drift"]) < 1e-13
+
+
+def test_bench_under_torch_distributed_run_exact_driver_command(mock_rccl):
+    """The driver's own N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W (here N = 2, LOCAL_RANK 1
+    folded onto the only device, stand-in transport)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **mock_rccl)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2",
+                          "--steps", "12", "--warmup", "4", "--cells", "80x50"], capture_output=True, text=True,
+                         timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 4 and d["config"]["elements"] == 8000
+    assert abs(d["config"]["mass_relative_drift"]) < 1e-13
