@@ -59,12 +59,12 @@ def _worker(rank, world, port, backend, out_dir):
         dist.destroy_process_group()
 
 
-def _single_domain(dt):
+def _single_domain(dt, order=ORDER):
     import blitzdg_amd.pyblitzdg as dg
     from blitzdg_amd import sw2d
     mesh = dg.MeshManager()
     mesh.buildBoxMesh(NX, NY)
-    nodes = dg.TriangleNodesProvisioner(ORDER, mesh)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
     ctx = nodes.dgContext()
     s = sw2d.Sw2dSolver(nodes=nodes)
     s.setState(*_fields(ctx.x, ctx.y))
@@ -218,7 +218,7 @@ def mock_rccl(tmp_path_factory):
     return {"BDG_RCCL_LIBRARY": str(lib), "BDG_MOCK_RCCL_DIR": str(out)}
 
 
-def _native_worker(rank, world, port, env, out_dir):
+def _native_worker(rank, world, port, env, out_dir, order=ORDER):
     import faulthandler
     faulthandler.enable()
     sys.path.insert(0, ROOT)
@@ -226,7 +226,7 @@ def _native_worker(rank, world, port, env, out_dir):
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port)})
     from blitzdg_amd.halo import NativeDistributedSw2d
-    d = NativeDistributedSw2d.box(NX, NY, ORDER, rank, world, device=0)
+    d = NativeDistributedSw2d.box(NX, NY, order, rank, world, device=0)
     try:
         d.set_initial_state(_fields)
         dt = 0.5 * d.compute_dt(0.65)          # global minimum through the communicator's all-reduce
@@ -242,19 +242,19 @@ def _native_worker(rank, world, port, env, out_dir):
         d.close()
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_native_multi_process_path_matches_single_domain(tmp_path, world, mock_rccl):
+@pytest.mark.parametrize("world,order", [(2, 4), (3, 4), (4, 4), (2, 7)])
+def test_native_multi_process_path_matches_single_domain(tmp_path, world, order, mock_rccl):
     """One process per rank exactly as under torchrun -- file rendezvous of the communicator id,
     bdg_sw2d_comm_init, the library's two-chain stage loop with grouped send / receive on the exchange
     stream, all-reduces for dt and mass -- with only librccl.so replaced (tests/mock_rccl). Owned states must
     equal the single-domain run bit for bit, and total mass must be conserved to round-off."""
     import torch.multiprocessing as mp
-    mp.start_processes(_native_worker, args=(world, _free_port(), mock_rccl, str(tmp_path)), nprocs=world, join=True,
-                       start_method="spawn")
+    mp.start_processes(_native_worker, args=(world, _free_port(), mock_rccl, str(tmp_path), order), nprocs=world,
+                       join=True, start_method="spawn")
     parts = [np.load(tmp_path / f"native{r}.npz") for r in range(world)]
     dt = float(parts[0]["dt"])
     assert all(float(p["dt"]) == dt for p in parts)
-    ref = _single_domain(dt)
+    ref = _single_domain(dt, order)
     seen = np.zeros(int(parts[0]["total"]), dtype=int)
     for p in parts:
         ids = p["ids"]
