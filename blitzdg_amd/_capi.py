@@ -121,6 +121,7 @@ _SIGNATURES = {
     "bdg_sw2d_get_state": (c_int, [_P, _P, _P, _P]),
     "bdg_sw2d_set_bathymetry": (c_int, [_P, _P]),
     "bdg_sw2d_output_fields": (c_int, [_P, _P, _P, _P, _P]),
+    "bdg_sw2d_output_tracer": (c_int, [_P, _P, _P]),
     "bdg_write_vtu_triangles": (c_int, [c_char_p, _P, _P, _P, c_int, c_char_p]),
     "bdg_sw2d_rhs": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int]),
     "bdg_sw2d_set_state4": (c_int, [_P, _P, _P, _P, _P]),

@@ -1177,6 +1177,23 @@ int bdg_sw2d_output_fields(bdg_sw2d* s, const double* IM, double* eta, double* u
     });
 }
 
+int bdg_sw2d_output_tracer(bdg_sw2d* s, const double* IM, double* tracer) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_output_tracer");
+        if (s->nf != 4) throw arg_error("bdg_sw2d_output_tracer: the solver has no tracer field");
+        if (!tracer) throw arg_error("bdg_sw2d_output_tracer: NULL output");
+        s->use();
+        if (IM) {
+            if (!s->outM.p) s->outM.alloc(static_cast<size_t>(s->Np) * s->Np, s->bytes);
+            hipCheck(hipMemcpyAsync(s->outM.p, IM, s->outM.n * sizeof(double), hipMemcpyHostToDevice, s->stream), "H2D copy");
+        }
+        // which = 3: field 3 divided by h, i.e. the concentration N = hN / h the reference script writes out
+        hipCheck(s->kt->output(s->qcur, nullptr, IM ? s->outM.p : nullptr, s->aux.p, s->ld, s->numOwned, 3, s->stream),
+                 "sw2d_output_kernel");
+        s->downloadRows(s->aux.p, tracer, s->Np);
+    });
+}
+
 int bdg_sw2d_set_bathymetry(bdg_sw2d* s, const double* H) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_set_bathymetry");

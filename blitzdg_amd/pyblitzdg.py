@@ -335,7 +335,10 @@ class VtkOutputter:
                 self._lattice = (IM, cut, xt, yt)
         IM, cut, xt, yt = self._lattice
         paths = []
-        for name, lat in zip(("eta", "u", "v"), solver.outputFields(IM)):
+        fields = list(zip(("eta", "u", "v"), solver.outputFields(IM)))
+        if getattr(solver, "fields", 3) == 4:
+            fields.append(("N", solver.outputTracer(IM)))       # the reference script's fourth output field
+        for name, lat in fields:
             ft = cut(lat)
             path = os.path.join(directory, self.generateFileName(name, tstep))
             check(lib.bdg_write_vtu_triangles(path.encode(), C.ptr(xt), C.ptr(yt), C.ptr(np.ascontiguousarray(ft)),

@@ -165,6 +165,13 @@ class Sw2dSolver:
         check(lib.bdg_sw2d_output_fields(self._h, C.ptr(m), *[C.ptr(o) for o in out]))
         return tuple(out)
 
+    def outputTracer(self, IM=None):
+        """Tracer concentration N = hN / h of a four-field solver's resident state, (Np, K)."""
+        m = C.as_f64(IM, (self.Np, self.Np), "IM") if IM is not None else None
+        out = np.empty((self.Np, self.K))
+        check(lib.bdg_sw2d_output_tracer(self._h, C.ptr(m), C.ptr(out)))
+        return out
+
     # ---- RHS (host in, host out)
     def computeRHS(self, h, hu, hv, filter=False):
         h, hu, hv = self._field(h, "h"), self._field(hu, "hu"), self._field(hv, "hv")

@@ -207,6 +207,9 @@ int bdg_sw2d_set_bathymetry(bdg_sw2d* s, const double* H);
  * bdg_trinodes_split_operators) they are interpolated to each element's equispaced lattice on the
  * device first (what splitElements does before a *.vtu is written). NULL outputs are skipped. */
 int bdg_sw2d_output_fields(bdg_sw2d* s, const double* IM, double* eta, double* u, double* v);
+/* Four-field solvers: the tracer concentration N = hN / h (what the reference's sw2d.py writes out), same
+ * optional lattice interpolation. */
+int bdg_sw2d_output_tracer(bdg_sw2d* s, const double* IM, double* tracer);
 /* Writes linear triangles ((3, num_triangles) x, y, field; one column per triangle) as a *.vtu. */
 int bdg_write_vtu_triangles(const char* path, const double* x, const double* y, const double* field,
                             int num_triangles, const char* field_name);

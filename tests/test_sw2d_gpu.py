@@ -833,3 +833,22 @@ def test_cpp_drivers_accept_a_synthetic_box_argument():
     for exe, args in (("sw2d-simple", ["box:12x7", "2", "1e9", "5"]), ("sw2d", ["box:12x7", "2", "5", "resident"])):
         out = subprocess.run([os.path.join(root, "bin", exe), *args], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "steps=5" in out.stdout, out.stdout + out.stderr
+
+
+def test_tracer_output_field_and_vtu(coarse_mesh, tmp_path):
+    """The script's fourth output field N = hN / h (sw2d.py:255-258) from the device-resident state."""
+    nodes = dg.TriangleNodesProvisioner(3, coarse_mesh)
+    t = tables_from_nodes(nodes)
+    h, hu, hv = seeded_fields(t["x"], t["y"])
+    hN = h * (0.5 + 0.25 * np.sin(2 * t["x"]))
+    s = sw2d.Sw2dSolver(nodes=nodes, fields=4)
+    s.setState4(h, hu, hv, hN)
+    assert np.array_equal(s.outputTracer(), hN / h)
+    assert np.array_equal(s.outputFields()[1], hu / h)
+    paths = dg.VtkOutputter(nodes).writeSolverFields(s, 12, directory=str(tmp_path))
+    assert [p.split("/")[-1] for p in paths] == ["eta0000012.vtu", "u0000012.vtu", "v0000012.vtu", "N0000012.vtu"]
+    ref = tmp_path / "ref.vtu"
+    dg.VtkOutputter(nodes).writeFieldToFile(str(ref), hN / h, "N")
+    assert open(ref, "rb").read() == open(paths[3], "rb").read()
+    with pytest.raises(BdgError, match="no tracer"):
+        sw2d.Sw2dSolver(nodes=nodes).outputTracer()
