@@ -3,10 +3,12 @@
 tracer and f-plane Coriolis, midpoint RK2 with the modal filter on every RHS, fixed dt from the
 initial state, blow-up check on max|h|) on the MI355X path, state resident in HBM.
 
-    python examples/sw2d_tracer.py [mesh.msh | box:NXxNY] [order] [steps]
+    python examples/sw2d_tracer.py [mesh.msh | box:NXxNY] [order] [steps] [outputDir]
 
 Differences from the script: the mesh defaults to tests/golden/coarse_box.msh (the script's
-input/R_8km_circle.msh is not shipped here), lengths are scaled to that box, and there is no VTK output.
+input/R_8km_circle.msh is not shipped here), lengths are scaled to that box, and the eta / u / v / N *.vtu
+files (sw2d.py:250-259) are written only when an output directory is given -- by the VTK-free writer, from
+fields computed on the device.
 """
 import os
 import sys
@@ -49,9 +51,15 @@ def main():
     mesh_arg = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tests", "golden", "coarse_box.msh")
     NOrder = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 200
+    outdir = sys.argv[4] if len(sys.argv) > 4 else None
     nodes, ctx, q, H, g, f, dt = setup(mesh_arg, NOrder)
     solver = sw2d.Sw2dSolver(nodes=nodes, g=g, fields=4, sources=dict(f=f, CD=0.0))
     solver.setState4(*q)
+    solver.setBathymetry(H)
+    outputter = dg.VtkOutputter(nodes)
+    if outdir:
+        os.makedirs(outdir, exist_ok=True)
+        outputter.writeSolverFields(solver, 0, directory=outdir)
     t, step = 0.0, 0
     while step < steps:
         n = min(50, steps - step)
@@ -62,6 +70,8 @@ def main():
         h_max = np.max(np.abs(h))
         if h_max > 1e8 or np.isnan(h_max):
             raise Exception("A numerical instability has occurred.")
+        if outdir:
+            outputter.writeSolverFields(solver, step, directory=outdir)
         print(f"t={t:.6g} step={step} eta_max={np.abs(h - H).max():.6g} |u|max={np.abs(hu / h).max():.6g} "
               f"N in [{(hN / h).min():.4f}, {(hN / h).max():.4f}]")
     return solver.getState4(), t
