@@ -413,10 +413,14 @@ struct bdg_sw2d {
                 ph.slope = -1.0; ph.dragSign = 1.0;   // swhelpers/rhs.py:300-309
             }
             p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
-            hipCheck(kt->stageMfma2Src(mode, p, ph, 0, st), what);
-            if (nf == 4) {
-                p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
-                hipCheck(kt->stageMfma2Src(mode, p, ph, 1, st), what);
+            if (nf == 4 && kt->mfmaMT <= 2 && !std::getenv("BDG_SW2D_TRACER_PASS")) {
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 3, st), what);     // N <= 6: the tracer rides in the same pass
+            } else {
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 0, st), what);
+                if (nf == 4) {
+                    p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
+                    hipCheck(kt->stageMfma2Src(mode, p, ph, 1, st), what);
+                }
             }
         } else if (variantD) {
             p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;

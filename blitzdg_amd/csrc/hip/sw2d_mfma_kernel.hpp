@@ -249,8 +249,11 @@ struct MfmaOps2 {
 // well: the operator image carries one more block of tiles, F' = Filter for the filtered RHS (the drivers
 // filter the whole RHS, sources included) or the identity, and R_c += F' S_c joins the volume term's k-steps,
 // where the lane already holds h, hu, hv of the node it needs.
-template <int N, int MODE, int PHYS = 0>
+// TRACER: a fourth accumulator set for the passive tracer hN (F4 = hN u, G4 = hN v) in the same pass -- where
+// the register budget allows it (MT <= 2, i.e. N <= 6); above that the tracer runs as its own pass below.
+template <int N, int MODE, int PHYS = 0, bool TRACER = false>
 __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(const StageParams p, const PhysParams ph) {
+    constexpr int NFLD = TRACER ? 4 : 3;
     using E = Elem<N>;
     using O = MfmaOps2<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
@@ -282,9 +285,9 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
         const unsigned k = live ? kTrue : kLast;
         const unsigned k8 = k * 8u, k4 = k * 4u;
 
-        mfma_acc_t acc[3][MT];
+        mfma_acc_t acc[NFLD][MT];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < NFLD; ++c)
 #pragma unroll
             for (int r = 0; r < MT; ++r) acc[c][r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
 
@@ -313,13 +316,16 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
             constexpr int VC = 3, NC = (KV + VC - 1) / VC;
             double hb[2][VC], hub[2][VC], hvb[2][VC];
             double sxb[2][PHYS != 0 ? VC : 1], syb[2][PHYS != 0 ? VC : 1], fcb[2][PHYS != 0 ? VC : 1];
+            double hnb[2][TRACER ? VC : 1];
             auto loadChunk = [&](int ch, int buf) {
 #pragma unroll
                 for (int s = 0; s < VC; ++s) {
                     const int t = ch * VC + s, m = 4 * t + static_cast<int>(q);
                     hb[buf][s] = 1.0; hub[buf][s] = 0.0; hvb[buf][s] = 0.0;
                     if constexpr (PHYS != 0) { sxb[buf][s] = 0.0; syb[buf][s] = 0.0; fcb[buf][s] = ph.fconst; }
+                    if constexpr (TRACER) hnb[buf][s] = 0.0;
                     if (t < KV && m < Np) {
+                        if constexpr (TRACER) hnb[buf][s] = ld_row(qin + 3 * plane + m * ld, k8);
                         hb[buf][s] = ld_row(qin + m * ld, k8);
                         hub[buf][s] = ld_row(qin + plane + m * ld, k8);
                         hvb[buf][s] = ld_row(qin + 2 * plane + m * ld, k8);
@@ -351,6 +357,15 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                         const double a1 = w * (rx * hu + ry * hv), b1 = w * (sx * hu + sy * hv);
                         const double a2 = w * (rx * F2 + ry * G2), b2 = w * (sx * F2 + sy * G2);
                         const double a3 = w * (rx * G2 + ry * G3), b3 = w * (sx * G2 + sy * G3);
+                        if constexpr (TRACER) {
+                            const double F4 = hnb[cur][s] * u, G4 = hnb[cur][s] * v;
+                            const double a4 = w * (rx * F4 + ry * G4), b4 = w * (sx * F4 + sy * G4);
+#pragma unroll
+                            for (int r2 = 0; r2 < MT; ++r2) {
+                                acc[3][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane], a4, acc[3][r2], 0, 0, 0);
+                                acc[3][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane], b4, acc[3][r2], 0, 0, 0);
+                            }
+                        }
                         if constexpr (PHYS != 0) {
                             const double cdn = ph.cd * fast_sqrt(u * u + v * v), gh = ph.slope * g * h;
                             const double s2 = -w * fma(gh, sxb[cur][s], fma(fcb[cur][s], hv, -(cdn * u)));
@@ -385,11 +400,13 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
             const double nxf = ld_row(ag + (4 + f) * ld, k8), nyf = ld_row(ag + (7 + f) * ld, k8);
             const double hfs = 0.5 * ld_row(ag + (10 + f) * ld, k8);
             double e1[KF], e2[KF], e3[KF], d1[KF], d2[KF], d3[KF];
+            double e4[TRACER ? KF : 1], d4[TRACER ? KF : 1];
             double lam = 0.0;
 #pragma unroll
             for (int tf = 0; tf < KF; ++tf) {
                 const int n = 4 * tf + static_cast<int>(q);
                 e1[tf] = e2[tf] = e3[tf] = d1[tf] = d2[tf] = d3[tf] = 0.0;
+                if constexpr (TRACER) e4[tf] = d4[tf] = 0.0;
                 if (n < Nfp) {
                     const int m = fmask_rt<N>(f, n);
                     const int id = fidx[f][tf];
@@ -398,6 +415,11 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                     const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
                     double hq = ld_row(qin, o8);
                     double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
+                    double nM = 0.0, nP = 0.0;
+                    if constexpr (TRACER) {
+                        nM = ld_row(qin + 3 * plane + m * ld, k8);
+                        nP = ld_row(qin + 3 * plane, o8);
+                    }
                     if constexpr (PHYS == 2) {
                         const double HM = ld_row(ph.H + m * ld, k8), HP = ld_row(ph.H, o8);
                         if ((btags >> (f * Nfp + n)) & 1) {   // open boundary (:348-353)
@@ -438,6 +460,10 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                     e1[tf] = d2[tf] * nxf + d3[tf] * nyf;
                     e2[tf] = (F2M - F2P) * nxf + (G2M - G2P) * nyf;
                     e3[tf] = (G2M - G2P) * nxf + (G3M - G3P) * nyf;
+                    if constexpr (TRACER) { // the tracer's '+' trace at a wall is the element's own value
+                        d4[tf] = nM - nP;
+                        e4[tf] = (nM * uM - nP * uP) * nxf + (nM * vM - nP * vP) * nyf;
+                    }
                 }
             }
             if constexpr (PHYS == 2) {
@@ -457,6 +483,8 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                     acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s1, acc[0][r], 0, 0, 0);
                     acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s2, acc[1][r], 0, 0, 0);
                     acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s3, acc[2][r], 0, 0, 0);
+                    if constexpr (TRACER)
+                        acc[3][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, hfs * (e4[tf] - lam * d4[tf]), acc[3][r], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -465,7 +493,7 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
         // ---- stage update / output, one field at a time
         if (live) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
+            for (int c = 0; c < NFLD; ++c) {
                 const long long fo = static_cast<long long>(c) * plane;
                 double oldv[MT][4], qv[MT][4];
                 if constexpr (MODE != MODE_RHS) {
@@ -500,7 +528,7 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                                 double sp = p.sponge;
                                 if constexpr (PHYS == 2)
                                     if (ph.spongeField) sp = ld_row(ph.spongeField + i * ld, k8);
-                                st_row(p.qout + fo + i * ld, k8, c == 0 ? val : sponge_relax(val, sp));
+                                st_row(p.qout + fo + i * ld, k8, (c == 0 || c == 3) ? val : sponge_relax(val, sp));
                             }
                         }
                     }

@@ -194,7 +194,7 @@ hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
 
 // matrix-core kernel with the momentum sources (operator image: MfmaOps2 + MT*KV tiles of F'); tracer = 1
 // launches the tracer pass instead (plain MfmaOps2 image), tracer = 2 the variant-B form (same image as the
-// sources). Orders above the unrolled kernels' range only.
+// sources), tracer = 3 sources and tracer fused (N <= 6). Orders above the unrolled kernels' range only.
 template <int MODE>
 hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
     if constexpr (!kMfmaSources) return hipErrorNotSupported;
@@ -206,7 +206,11 @@ hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer
     const unsigned waves = tracer == 1 ? 3u : static_cast<unsigned>(BDG_MFMA2_WAVES);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(waves, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
-    if (tracer == 1) hipLaunchKernelGGL((sw2d_stage_mfma2_tracer_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
+    if (tracer == 3) { // sources + tracer in one pass (MT <= 2)
+        if constexpr (MfmaOps2<kN>::MT <= 2)
+            hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE, 1, true>), dim3(grid), dim3(256), ldsBytes, stream, p, ph);
+        else return hipErrorNotSupported;
+    } else if (tracer == 1) hipLaunchKernelGGL((sw2d_stage_mfma2_tracer_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
     else if (tracer == 2) hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE, 2>), dim3(grid), dim3(256), ldsBytes, stream, p, ph);
     else hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE, 1>), dim3(grid), dim3(256), ldsBytes, stream, p, ph);
     return hipGetLastError();
