@@ -93,7 +93,8 @@ struct PhysParams {
     double tide;
 };
 
-template <int N, int MODE, int PHYS = 0>
+// TRACER: the passive tracer hN (field 3; F4 = hN u, G4 = hN v, no sources) in the same pass.
+template <int N, int MODE, int PHYS = 0, bool TRACER = false>
 __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParams p, const PhysParams ph) {
     using E = Elem<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN;
@@ -114,12 +115,13 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     int idx[NFN];
 #pragma unroll
     for (int j = 0; j < NFN; ++j) idx[j] = ld_row(p.vmapP + j * ld, k4);
-    double h[Np], hu[Np], hv[Np];
+    double h[Np], hu[Np], hv[Np], hN[TRACER ? Np : 1];
 #pragma unroll
     for (int n = 0; n < Np; ++n) {
         h[n] = ld_row(qin + n * ld, k8);
         hu[n] = ld_row(qin + plane + n * ld, k8);
         hv[n] = ld_row(qin + 2 * plane + n * ld, k8);
+        if constexpr (TRACER) hN[n] = ld_row(qin + 3 * plane + n * ld, k8);
     }
     const double* __restrict__ ag = p.ageo;
     const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8), sy = ld_row(ag + 3 * ld, k8);
@@ -144,20 +146,25 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     // its first use to save registers and the wave pays one memory round trip per node.
     __builtin_amdgcn_sched_barrier(0);
     // ---- neighbour ('+') traces: gathers from the same planes, served by L1/L2
-    double hP[NFN], huP[NFN], hvP[NFN];
+    double hP[NFN], huP[NFN], hvP[NFN], hNP[TRACER ? NFN : 1];
 #pragma unroll
     for (int j = 0; j < NFN; ++j) {
         const unsigned o8 = static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u;
         hP[j] = ld_row(qin, o8);
         huP[j] = ld_row(qin + plane, o8);
         hvP[j] = ld_row(qin + 2 * plane, o8);
+        if constexpr (TRACER) hNP[j] = ld_row(qin + 3 * plane, o8);
     }
     __builtin_amdgcn_sched_barrier(0);
 
     const double g = p.g, halfg = 0.5 * p.g;
-    double R1[Np], R2[Np], R3[Np];
+    double R1[Np], R2[Np], R3[Np], R4[TRACER ? Np : 1];
 #pragma unroll
     for (int i = 0; i < Np; ++i) R1[i] = R2[i] = R3[i] = 0.0;
+    if constexpr (TRACER) {
+#pragma unroll
+        for (int i = 0; i < Np; ++i) R4[i] = 0.0;
+    }
     if constexpr (PHYS != 0) { // momentum sources, node by node
 #pragma unroll
         for (int m = 0; m < Np; ++m) {
@@ -208,18 +215,23 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             const double s1 = half_fs * (dhu * nxf + dhv * nyf - lam * dh);
             const double s2 = half_fs * ((F2M - F2P) * nxf + (G2M - G2P) * nyf - lam * dhu);
             const double s3 = half_fs * ((G2M - G2P) * nxf + (G3M - G3P) * nyf - lam * dhv);
+            double s4 = 0.0;
+            if constexpr (TRACER) // the tracer's '+' trace at a wall is the element's own value
+                s4 = half_fs * ((hN[m] * uM[n] - hNP[j] * uP[n]) * nxf + (hN[m] * vM[n] - hNP[j] * vP[n]) * nyf -
+                                lam * (hN[m] - hNP[j]));
 #pragma unroll
             for (int i = 0; i < Np; ++i) {
                 const double lj = ops[AffineOps<N>::OFF_LIFT + j * Np + i];
                 R1[i] = fma(lj, s1, R1[i]);
                 R2[i] = fma(lj, s2, R2[i]);
                 R3[i] = fma(lj, s3, R3[i]);
+                if constexpr (TRACER) R4[i] = fma(lj, s4, R4[i]);
             }
         }
     }
 
     // ---- stage inputs that are only needed at the very end: issue now, land during the volume loop
-    double old1[Np], old2[Np], old3[Np];
+    double old1[Np], old2[Np], old3[Np], old4[TRACER ? Np : 1];
     if constexpr (MODE == MODE_LSERK) {
         const double* __restrict__ rs = p.res;
 #pragma unroll
@@ -227,6 +239,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             old1[i] = ld_row(rs + i * ld, k8);
             old2[i] = ld_row(rs + plane + i * ld, k8);
             old3[i] = ld_row(rs + 2 * plane + i * ld, k8);
+            if constexpr (TRACER) old4[i] = ld_row(rs + 3 * plane + i * ld, k8);
         }
     } else if constexpr (MODE == MODE_COMBINE) {
         const double* __restrict__ qb = p.qbase;
@@ -235,6 +248,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             old1[i] = ld_row(qb + i * ld, k8);
             old2[i] = ld_row(qb + plane + i * ld, k8);
             old3[i] = ld_row(qb + 2 * plane + i * ld, k8);
+            if constexpr (TRACER) old4[i] = ld_row(qb + 3 * plane + i * ld, k8);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -253,12 +267,19 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
         const double a1 = -(rx * hu[m] + ry * hv[m]), b1 = -(sx * hu[m] + sy * hv[m]);
         const double a2 = -(rx * F2 + ry * G2), b2 = -(sx * F2 + sy * G2);
         const double a3 = -(rx * G2 + ry * G3), b3 = -(sx * G2 + sy * G3);
+        double a4 = 0.0, b4 = 0.0;
+        if constexpr (TRACER) {
+            const double F4 = hN[m] * u, G4 = hN[m] * v;
+            a4 = -(rx * F4 + ry * G4);
+            b4 = -(sx * F4 + sy * G4);
+        }
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
             const double dr = ops[AffineOps<N>::OFF_D + 2 * (m * Np + i)];
             R1[i] = fma(dr, a1, R1[i]);
             R2[i] = fma(dr, a2, R2[i]);
             R3[i] = fma(dr, a3, R3[i]);
+            if constexpr (TRACER) R4[i] = fma(dr, a4, R4[i]);
         }
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             R1[i] = fma(ds, b1, R1[i]);
             R2[i] = fma(ds, b2, R2[i]);
             R3[i] = fma(ds, b3, R3[i]);
+            if constexpr (TRACER) R4[i] = fma(ds, b4, R4[i]);
         }
     }
 
@@ -286,6 +308,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
         applyFilter(R1);
         applyFilter(R2);
         applyFilter(R3);
+        if constexpr (TRACER) applyFilter(R4);
     }
 
     // ---- stage update / output
@@ -296,6 +319,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             st_row(o + i * ld, k8, R1[i]);
             st_row(o + plane + i * ld, k8, R2[i]);
             st_row(o + 2 * plane + i * ld, k8, R3[i]);
+            if constexpr (TRACER) st_row(o + 3 * plane + i * ld, k8, R4[i]);
         }
     } else if constexpr (MODE == MODE_LSERK) {
         double* __restrict__ rs = p.res;
@@ -312,6 +336,11 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             st_row(o + i * ld, k8, h[i] + b * n1);
             st_row(o + plane + i * ld, k8, hu[i] + b * n2);
             st_row(o + 2 * plane + i * ld, k8, hv[i] + b * n3);
+            if constexpr (TRACER) {
+                const double n4 = a * old4[i] + dt * R4[i];
+                st_row(rs + 3 * plane + i * ld, k8, n4);
+                st_row(o + 3 * plane + i * ld, k8, hN[i] + b * n4);
+            }
         }
     } else {
         double* __restrict__ o = p.qout;
@@ -321,6 +350,7 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             st_row(o + i * ld, k8, a * old1[i] + b * h[i] + c * R1[i]);
             st_row(o + plane + i * ld, k8, sponge_relax(a * old2[i] + b * hu[i] + c * R2[i], p.sponge));
             st_row(o + 2 * plane + i * ld, k8, sponge_relax(a * old3[i] + b * hv[i] + c * R3[i], p.sponge));
+            if constexpr (TRACER) st_row(o + 3 * plane + i * ld, k8, a * old4[i] + b * hN[i] + c * R4[i]);
         }
     }
 }

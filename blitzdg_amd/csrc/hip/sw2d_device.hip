@@ -399,10 +399,14 @@ struct bdg_sw2d {
             // filtered RHS: plain operators, Filter applied to flux terms + sources at the end
             ph.fmat = filter ? filterT.p : nullptr;
             p.opsAffine = opsAffine.p;
-            hipCheck(kt->stageAffineSrc(mode, p, ph, st), what);
-            if (nf == 4) { // the tracer has no sources: pre-filtered operators as in variant A
-                p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
-                hipCheck(kt->stageTracer(mode, p, st), what);
+            if (nf == 4 && !std::getenv("BDG_SW2D_TRACER_PASS")) {
+                hipCheck(kt->stageAffineSrc(mode, p, ph, 1, st), what);    // the tracer rides in the same pass
+            } else {
+                hipCheck(kt->stageAffineSrc(mode, p, ph, 0, st), what);
+                if (nf == 4) { // own pass; the tracer has no sources: pre-filtered operators as in variant A
+                    p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
+                    hipCheck(kt->stageTracer(mode, p, st), what);
+                }
             }
         } else if (variantD && mfmaSources) {
             // N >= 6: three conserved fields with sources on the matrix cores, then the tracer pass

@@ -30,7 +30,7 @@ struct KernelTable {
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);
     // unrolled affine kernel + momentum sources (3 fields; N <= 6), the fast path of variants C/D
-    hipError_t (*stageAffineSrc)(int mode, const StageParams& p, const PhysParams& ph, hipStream_t stream);
+    hipError_t (*stageAffineSrc)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);
     // tracer equation alone (field 3 of a four-field state), unrolled; N <= 6
     hipError_t (*stageTracer)(int mode, const StageParams& p, hipStream_t stream);
     // variant B (depth, star states, open boundary, global Lax-Friedrichs speed, sources): speed pass over

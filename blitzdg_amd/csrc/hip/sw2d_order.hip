@@ -79,13 +79,18 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
 
 // unrolled kernel with the momentum source terms (orders where it exists: N <= 6)
 template <int MODE>
-hipError_t launchAffineSrc(const StageParams& p, const PhysParams& ph, hipStream_t stream) {
+hipError_t launchAffineSrc(const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
     if constexpr (kNoUnrolledSources) return hipErrorNotSupported;
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kBlock - 1) / kBlock);
-    if (ph.fmat) hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 2>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
-    else hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 1>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
+    if (tracer) {
+        if (ph.fmat) hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 2, true>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
+        else hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 1, true>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
+    } else {
+        if (ph.fmat) hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 2>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
+        else hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 1>), dim3(grid), dim3(kBlock), 0, stream, p, ph);
+    }
     return hipGetLastError();
     }
 }
@@ -110,11 +115,12 @@ hipError_t stageTracer(int mode, const StageParams& p, hipStream_t stream) {
     }
 }
 
-hipError_t stageAffineSrc(int mode, const StageParams& p, const PhysParams& ph, hipStream_t stream) {
+// tracer != 0: four-field state, the tracer equation in the same pass
+hipError_t stageAffineSrc(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
     switch (mode) {
-    case MODE_RHS: return launchAffineSrc<MODE_RHS>(p, ph, stream);
-    case MODE_LSERK: return launchAffineSrc<MODE_LSERK>(p, ph, stream);
-    case MODE_COMBINE: return launchAffineSrc<MODE_COMBINE>(p, ph, stream);
+    case MODE_RHS: return launchAffineSrc<MODE_RHS>(p, ph, tracer, stream);
+    case MODE_LSERK: return launchAffineSrc<MODE_LSERK>(p, ph, tracer, stream);
+    case MODE_COMBINE: return launchAffineSrc<MODE_COMBINE>(p, ph, tracer, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -852,3 +852,23 @@ def test_tracer_output_field_and_vtu(coarse_mesh, tmp_path):
     assert open(ref, "rb").read() == open(paths[3], "rb").read()
     with pytest.raises(BdgError, match="no tracer"):
         sw2d.Sw2dSolver(nodes=nodes).outputTracer()
+
+
+@pytest.mark.parametrize("case", ["coarse_box_N4", "coarse_box_N6"])
+def test_tracer_in_its_own_pass_as_cross_check(case, monkeypatch):
+    """By default the tracer equation rides in the three-field kernel as a fourth accumulator set (N <= 6);
+    BDG_SW2D_TRACER_PASS=1 runs it as its own pass (the form N = 7, 8 always use). Same reference output."""
+    monkeypatch.setenv("BDG_SW2D_TRACER_PASS", "1")
+    d = _load4(case)
+    t = {k: d[k] for k in ("Dr", "Ds", "Lift", "Filter", "rx", "sx", "ry", "sy", "nx", "ny", "Fscale", "vmapM", "vmapP",
+                           "mapW")}
+    t["order"] = int(d["order"])
+    s = sw2d.Sw2dSolver(tables=t, g=float(d["g"]), fields=4,
+                        sources={"zx": d["zx"], "zy": d["zy"], "f": d["f"], "CD": float(d["CD"])})
+    r = s.computeRHS4(d["h"], d["hu"], d["hv"], d["hN"])
+    scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3, 4))
+    for i in range(4):
+        assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < RHS_TOL
+    rf = s.computeRHS4(d["h"], d["hu"], d["hv"], d["hN"], filter=True)
+    for i in range(4):
+        assert np.abs(rf[i] - d["Filter"] @ d[f"rhs{i + 1}"]).max() / scale < RHS_TOL
