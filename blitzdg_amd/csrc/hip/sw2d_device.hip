@@ -457,9 +457,9 @@ struct bdg_sw2d {
     double lamTideFor = 0.0;
     double nextEvalTime = 0.0;         // model time of the evaluation that will follow the current launch
     // elements below which the matrix-core kernel is the faster one, per order (measured crossovers:
-    // N=2 between 30 k and 61 k, N=3 near 125 k, N=4 between 125 k and 250 k; N=1 never ahead; N=5 runs on
+    // N=2 near 10 k, N=3 near 125 k, N=4 between 125 k and 250 k; N=1 never ahead; N=5 runs on
     // the matrix cores at every size)
-    static constexpr int kSmallLaunch[6] = {0, 4000, 40000, 100000, 160000, 0};
+    static constexpr int kSmallLaunch[6] = {0, 4000, 10000, 100000, 160000, 0};
     bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
 
     void launchRhs(const double* qin, double* out, bool filter) {
@@ -1591,8 +1591,11 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         s->commWorld = world;
         s->peers = peers;
         hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
+        // These four events only order kernels of the two streams of THIS device against each other (the
+        // kernels' own end-of-kernel release is device-wide); the system-scope fence of a default event record
+        // is not needed for that and costs 2-3 us per stage.
         for (hipEvent_t* e : {&s->evA[0], &s->evA[1], &s->evB[0], &s->evB[1]})
-            hipCheck(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
+            hipCheck(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate");
         const size_t rows = static_cast<size_t>(s->nf) * s->Np;
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
