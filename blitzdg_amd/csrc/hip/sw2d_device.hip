@@ -272,7 +272,8 @@ struct bdg_sw2d {
     int affineVariant = 0; // 0: unrolled, register-resident state; 2/3: unrolled, streamed state at 2/3 waves
                            // per SIMD; 1: rolled, one field per wave; 4: rolled, three fields per lane; 5: matrix cores (MFMA f64),
                            // whole tile unrolled; 6: matrix cores, face-by-face / chunked schedule at 2 waves per SIMD
-    DevBuf<int> vmapP, perm, istage, sendSlots;
+    DevBuf<int> vmapP, perm, istage, sendSlots, haloSendOf;
+    bool haloFusable = false;  // every sent element is a partition-boundary element with at most three records
     int numInterior = 0, numOwned = 0, numSend = 0; // element partition: [interior | boundary | ghost]
     // native halo exchange (RCCL over xGMI): one send and one receive range per neighbour rank
     struct Peer { int rank, sendStart, sendCount, recvStart, recvCount; };
@@ -512,6 +513,28 @@ struct bdg_sw2d {
         hipCheck(hipGetLastError(), "halo_unpack_kernel");
     }
 
+    // True when the partition-boundary launch of an exchanged stage can do the halo staging itself (three-field
+    // straight-sided solver whose boundary strip runs on the matrix-core kernel v1).
+    bool halosFold() const {
+        return haloFusable && affine && !variantB && !variantD && !variantForced && N <= 4 &&
+               numOwned - numInterior < kSmallLaunch[N] && !std::getenv("BDG_SW2D_HALO_KERNELS");
+    }
+    // LSERK4 stage of the partition-boundary elements: reads ghost traces from recv, writes send records
+    void launchBoundaryStageFolded(hipStream_t on, const double* recv, double* send) {
+        const int st = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
+        bdg_dev::StageParams p = baseParams();
+        p.kbegin = numInterior;
+        p.qin = qcur; p.qout = qalt; p.res = res.p;
+        p.ca = blitzdg::LSERK4::rk4a[st]; p.cb = blitzdg::LSERK4::rk4b[st]; p.cc = dtStage;
+        p.opsAffine = opsMfma.p;
+        p.haloRecv = recv; p.haloSend = send; p.haloSendOf = haloSendOf.p;
+        p.haloOwned = numOwned; p.haloRows = nf * Np;
+        hipCheck(kt->stageMfmaHalo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
+        std::swap(qcur, qalt);
+        ++stageCount;
+        if (st == blitzdg::LSERK4::numStages - 1) timeNow += dtStage;
+    }
+
     // LSERK4 stages of a partitioned run, all on the device, as two concurrent chains:
     //   compute stream  A:  wait B(s-1) -> [interior elements of stage s] -> signal A(s)
     //   exchange stream B:  pack(s) -> grouped ncclSend/ncclRecv with every neighbour -> unpack(s)
@@ -532,6 +555,10 @@ struct bdg_sw2d {
         hipCheck(hipEventRecord(evA[1], stream), "hipEventRecord");
         hipCheck(hipStreamWaitEvent(commStream, evA[1], 0), "hipStreamWaitEvent");
         bool haveA = false, haveB = false;
+        // With the staging folded into the boundary kernel, chain B is: exchange -> boundary kernel (which reads
+        // the received records and writes the next send records); only the very first exchange needs a pack.
+        const bool fold = halosFold();
+        if (fold) launchPack(sendBuf.p, commStream);
         for (int i = 0; i < numStages; ++i) {
             const int cur = i & 1, prev = cur ^ 1;
             // ---- chain A
@@ -539,7 +566,7 @@ struct bdg_sw2d {
             launchLserkStage(0);
             hipCheck(hipEventRecord(evA[cur], stream), "hipEventRecord");
             // ---- chain B
-            launchPack(sendBuf.p, commStream);
+            if (!fold) launchPack(sendBuf.p, commStream);
             if (!peers.empty()) {
                 RcclApi& nc = rccl();
                 ncclCheck(nc.GroupStart(), "ncclGroupStart");
@@ -555,9 +582,10 @@ struct bdg_sw2d {
                 }
                 ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
             }
-            launchUnpack(recvBuf.p, commStream);
+            if (!fold) launchUnpack(recvBuf.p, commStream);
             if (haveA) hipCheck(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
-            launchLserkStage(1, commStream);                   // partition-boundary elements, advance
+            if (fold) launchBoundaryStageFolded(commStream, recvBuf.p, sendBuf.p);
+            else launchLserkStage(1, commStream);              // partition-boundary elements, advance
             hipCheck(hipEventRecord(evB[cur], commStream), "hipEventRecord");
             haveA = haveB = true;
         }
@@ -1494,6 +1522,25 @@ int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const i
         s->numInterior = num_interior;
         s->numOwned = num_owned;
         s->numSend = num_send;
+        // for the boundary kernel with the halo staging folded in: the (up to three) send records of each
+        // partition-boundary element
+        const int nB = num_owned - num_interior;
+        std::vector<int> of(static_cast<size_t>(3) * std::max(nB, 1), -1);
+        bool ok = true;
+        for (int r = 0; r < num_send && ok; ++r) {
+            const int b = send_elements[r] - num_interior;
+            if (b < 0) { ok = false; break; }
+            int t = 0;
+            while (t < 3 && of[3 * b + t] >= 0) ++t;
+            if (t == 3) { ok = false; break; }
+            of[3 * b + t] = r;
+        }
+        s->haloSendOf.release();
+        s->haloFusable = ok && nB > 0;
+        if (s->haloFusable) {
+            s->haloSendOf.alloc(of.size(), s->bytes);
+            hipCheck(hipMemcpy(s->haloSendOf.p, of.data(), of.size() * sizeof(int), hipMemcpyHostToDevice), "send table upload");
+        }
     });
 }
 
@@ -1672,6 +1719,9 @@ int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int
             hipCheck(hipEventRecord(s->evA[1], s->stream), "hipEventRecord");
             hipCheck(hipStreamWaitEvent(s->commStream, s->evA[1], 0), "hipStreamWaitEvent");
         }
+        // pack / unpack folded into the boundary kernel where every part can do it (see launchLserkStagesExchanged)
+        bool fold = true;
+        for (int r = 0; r < num_parts; ++r) fold = fold && parts[r]->halosFold();
         for (int i = 0; i < num_stages; ++i) {
             const int cur = i & 1, prev = cur ^ 1;
             const bool first = i == 0;
@@ -1681,10 +1731,12 @@ int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int
                 if (!first) hipCheck(hipStreamWaitEvent(s->stream, s->evB[prev], 0), "hipStreamWaitEvent");
                 s->launchLserkStage(0);
                 hipCheck(hipEventRecord(s->evA[cur], s->stream), "hipEventRecord");
-                if (!first)                                   // neighbours are done reading our send buffer
-                    for (const bdg_sw2d::Peer& pr : s->peers)
-                        hipCheck(hipStreamWaitEvent(s->commStream, parts[pr.rank]->evCopied[prev], 0), "hipStreamWaitEvent");
-                s->launchPack(s->sendBuf.p, s->commStream);
+                if (!fold || first) {
+                    if (!first)                               // neighbours are done reading our send buffer
+                        for (const bdg_sw2d::Peer& pr : s->peers)
+                            hipCheck(hipStreamWaitEvent(s->commStream, parts[pr.rank]->evCopied[prev], 0), "hipStreamWaitEvent");
+                    s->launchPack(s->sendBuf.p, s->commStream);
+                }                                             // (folded: boundary(i-1) wrote the records, same stream)
                 hipCheck(hipEventRecord(s->evPacked[cur], s->commStream), "hipEventRecord");
             }
             for (int r = 0; r < num_parts; ++r) {           // pull the ghosts
@@ -1710,9 +1762,16 @@ int bdg_sw2d_group_lserk4_stages(bdg_sw2d** parts, int num_parts, double dt, int
             for (int r = 0; r < num_parts; ++r) {           // chain B: unpack, boundary elements
                 bdg_sw2d* s = parts[r];
                 s->use();
-                s->launchUnpack(s->recvBuf.p, s->commStream);
+                if (!fold) s->launchUnpack(s->recvBuf.p, s->commStream);
                 if (!first) hipCheck(hipStreamWaitEvent(s->commStream, s->evA[prev], 0), "hipStreamWaitEvent");
-                s->launchLserkStage(1, s->commStream);
+                if (fold) {
+                    // the kernel overwrites the send records: every neighbour must have pulled this stage's first
+                    for (const bdg_sw2d::Peer& pr : s->peers)
+                        hipCheck(hipStreamWaitEvent(s->commStream, parts[pr.rank]->evCopied[cur], 0), "hipStreamWaitEvent");
+                    s->launchBoundaryStageFolded(s->commStream, s->recvBuf.p, s->sendBuf.p);
+                } else {
+                    s->launchLserkStage(1, s->commStream);
+                }
                 hipCheck(hipEventRecord(s->evB[cur], s->commStream), "hipEventRecord");
             }
         }

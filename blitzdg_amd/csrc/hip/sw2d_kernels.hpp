@@ -71,6 +71,14 @@ struct StageParams {
     double ca, cb, cc;
     double one;          // 1.0 (run-time constant used to stop value reuse across phases)
     double sponge;       // MODE_COMBINE: momentum relaxation x /= (1 + sponge x^2) after the update (0: off)
+    // Partition-boundary launches with the halo staging folded in (matrix-core kernel, HALO = true): neighbour
+    // traces that live in ghost slots (>= haloOwned) are read from the received element-major records, and the
+    // new state of each element is also written to its (up to three) records of the send buffer.
+    const double* haloRecv; // (ghosts, haloRows) records as the neighbours packed them
+    double* haloSend;       // (numSend, haloRows)
+    const int* haloSendOf;  // 3 send-record indices per element of [kbegin, kend), -1 = none
+    int haloOwned;          // first ghost slot
+    int haloRows;           // doubles per record = fields * Np
 };
 
 // Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):

@@ -21,6 +21,8 @@ struct KernelTable {
     // matrix-core path (v_mfma_f64_16x16x4_f64), straight-sided elements; needs ldsBytes of dynamic LDS
     int mfmaOpsDoubles, mfmaMT, mfmaKV, mfmaKS;
     hipError_t (*stageMfma)(int mode, const StageParams& p, hipStream_t stream);
+    // MODE_LSERK on partition-boundary elements with pack / unpack folded in (StageParams::halo*)
+    hipError_t (*stageMfmaHalo)(const StageParams& p, hipStream_t stream);
     int mfma2OpsDoubles, mfma2KF; // face-by-face schedule (lift tiles padded per face)
     hipError_t (*stageMfma2)(int mode, const StageParams& p, hipStream_t stream);
     // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the

@@ -39,7 +39,9 @@ struct MfmaOps {
     static constexpr int DOUBLES = OFF_LIFT + MT * KS * 64;
 };
 
-template <int N, int MODE>
+// HALO (with MODE_LSERK, partition-boundary launches): pack and unpack of the ghost exchange folded in, see
+// StageParams::haloRecv.
+template <int N, int MODE, bool HALO = false>
 __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(const StageParams p) {
     using E = Elem<N>;
     using O = MfmaOps<N>;
@@ -124,9 +126,24 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
                     const int id = ld_row(p.vmapP + jf * ld, k4);
                     const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
                                  hvM = ld_row(qin + 2 * plane + m * ld, k8);
-                    const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
-                    const double hq = ld_row(qin, o8);
-                    double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
+                    const unsigned idp = static_cast<unsigned>(id < 0 ? -(id + 1) : id), o8 = idp * 8u;
+                    double hq, huq, hvq;
+                    bool ghost = false;
+                    unsigned rec8 = 0;
+                    if constexpr (HALO) {
+                        const unsigned row = idp / static_cast<unsigned>(ld), slot = idp - row * static_cast<unsigned>(ld);
+                        ghost = slot >= static_cast<unsigned>(p.haloOwned);
+                        rec8 = ((slot - static_cast<unsigned>(p.haloOwned)) * static_cast<unsigned>(p.haloRows) + row) * 8u;
+                    }
+                    if (ghost) { // the neighbour's record as it arrived: [field][node]
+                        hq = ld_row(p.haloRecv, rec8);
+                        huq = ld_row(p.haloRecv + Np, rec8);
+                        hvq = ld_row(p.haloRecv + 2 * Np, rec8);
+                    } else {
+                        hq = ld_row(qin, o8);
+                        huq = ld_row(qin + plane, o8);
+                        hvq = ld_row(qin + 2 * plane, o8);
+                    }
                     if (id < 0) { // reflective wall: no normal flow
                         const double un = huM * nxf + hvM * nyf;
                         huq = huM - 2 * nxf * un;
@@ -178,6 +195,13 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
 
         // ---- stage update / output: this lane holds output nodes i = 16r + q + 4*reg of its element
         if (live) {
+            int sendRec[3] = {-1, -1, -1};
+            if constexpr (HALO) {
+                const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
+                sendRec[0] = p.haloSendOf[b3];
+                sendRec[1] = p.haloSendOf[b3 + 1];
+                sendRec[2] = p.haloSendOf[b3 + 2];
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const long long fo = static_cast<long long>(c) * plane;
@@ -204,8 +228,15 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
                                 st_row(p.rhs + fo + i * ld, k8, R);
                             } else if constexpr (MODE == MODE_LSERK) {
                                 const double n1 = p.ca * oldv[reg] + p.cc * R;
+                                const double qn = qv[reg] + p.cb * n1;
                                 st_row(p.res + fo + i * ld, k8, n1);
-                                st_row(p.qout + fo + i * ld, k8, qv[reg] + p.cb * n1);
+                                st_row(p.qout + fo + i * ld, k8, qn);
+                                if constexpr (HALO) {
+#pragma unroll
+                                    for (int sr = 0; sr < 3; ++sr)
+                                        if (sendRec[sr] >= 0)
+                                            p.haloSend[static_cast<size_t>(sendRec[sr]) * p.haloRows + c * Np + i] = qn;
+                                }
                             } else {
                                 const double val = p.ca * oldv[reg] + p.cb * qv[reg] + p.cc * R;
                                 st_row(p.qout + fo + i * ld, k8, c == 0 ? val : sponge_relax(val, p.sponge));
