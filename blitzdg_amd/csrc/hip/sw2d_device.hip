@@ -514,10 +514,10 @@ struct bdg_sw2d {
     }
 
     // True when the partition-boundary launch of an exchanged stage can do the halo staging itself (three-field
-    // straight-sided solver whose boundary strip runs on the matrix-core kernel v1).
+    // straight-sided solver whose boundary strip runs on a matrix-core kernel).
     bool halosFold() const {
-        return haloFusable && affine && !variantB && !variantD && !variantForced && N <= 4 &&
-               numOwned - numInterior < kSmallLaunch[N] && !std::getenv("BDG_SW2D_HALO_KERNELS");
+        if (!haloFusable || !affine || variantB || variantD || variantForced || std::getenv("BDG_SW2D_HALO_KERNELS")) return false;
+        return N >= 5 || numOwned - numInterior < kSmallLaunch[N]; // the strip runs on a matrix-core kernel
     }
     // LSERK4 stage of the partition-boundary elements: reads ghost traces from recv, writes send records
     void launchBoundaryStageFolded(hipStream_t on, const double* recv, double* send) {
@@ -526,10 +526,15 @@ struct bdg_sw2d {
         p.kbegin = numInterior;
         p.qin = qcur; p.qout = qalt; p.res = res.p;
         p.ca = blitzdg::LSERK4::rk4a[st]; p.cb = blitzdg::LSERK4::rk4b[st]; p.cc = dtStage;
-        p.opsAffine = opsMfma.p;
         p.haloRecv = recv; p.haloSend = send; p.haloSendOf = haloSendOf.p;
         p.haloOwned = numOwned; p.haloRows = nf * Np;
-        hipCheck(kt->stageMfmaHalo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
+        if (N >= 5) {
+            p.opsAffine = opsMfma2.p;
+            hipCheck(kt->stageMfma2Halo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
+        } else {
+            p.opsAffine = opsMfma.p;
+            hipCheck(kt->stageMfmaHalo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
+        }
         std::swap(qcur, qalt);
         ++stageCount;
         if (st == blitzdg::LSERK4::numStages - 1) timeNow += dtStage;

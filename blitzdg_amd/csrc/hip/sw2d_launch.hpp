@@ -23,6 +23,7 @@ struct KernelTable {
     hipError_t (*stageMfma)(int mode, const StageParams& p, hipStream_t stream);
     // MODE_LSERK on partition-boundary elements with pack / unpack folded in (StageParams::halo*)
     hipError_t (*stageMfmaHalo)(const StageParams& p, hipStream_t stream);
+    hipError_t (*stageMfma2Halo)(const StageParams& p, hipStream_t stream); // the same on the face-by-face kernel (N >= 5)
     int mfma2OpsDoubles, mfma2KF; // face-by-face schedule (lift tiles padded per face)
     hipError_t (*stageMfma2)(int mode, const StageParams& p, hipStream_t stream);
     // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the

@@ -282,7 +282,9 @@ struct MfmaOps2 {
 // where the lane already holds h, hu, hv of the node it needs.
 // TRACER: a fourth accumulator set for the passive tracer hN (F4 = hN u, G4 = hN v) in the same pass -- where
 // the register budget allows it (MT <= 2, i.e. N <= 6); above that the tracer runs as its own pass below.
-template <int N, int MODE, int PHYS = 0, bool TRACER = false>
+// HALO (MODE_LSERK, PHYS = 0, partition-boundary launches): ghost traces read from the received records and the
+// new state written to the send records, as in sw2d_stage_mfma_kernel.
+template <int N, int MODE, int PHYS = 0, bool TRACER = false, bool HALO = false>
 __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(const StageParams p, const PhysParams ph) {
     constexpr int NFLD = TRACER ? 4 : 3;
     using E = Elem<N>;
@@ -443,9 +445,24 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                     const int id = fidx[f][tf];
                     double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
                            hvM = ld_row(qin + 2 * plane + m * ld, k8);
-                    const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
-                    double hq = ld_row(qin, o8);
-                    double huq = ld_row(qin + plane, o8), hvq = ld_row(qin + 2 * plane, o8);
+                    const unsigned idp = static_cast<unsigned>(id < 0 ? -(id + 1) : id), o8 = idp * 8u;
+                    double hq, huq, hvq;
+                    bool ghost = false;
+                    unsigned rec8 = 0;
+                    if constexpr (HALO) {
+                        const unsigned row = idp / static_cast<unsigned>(ld), slot = idp - row * static_cast<unsigned>(ld);
+                        ghost = slot >= static_cast<unsigned>(p.haloOwned);
+                        rec8 = ((slot - static_cast<unsigned>(p.haloOwned)) * static_cast<unsigned>(p.haloRows) + row) * 8u;
+                    }
+                    if (ghost) { // the neighbour's record as it arrived: [field][node]
+                        hq = ld_row(p.haloRecv, rec8);
+                        huq = ld_row(p.haloRecv + Np, rec8);
+                        hvq = ld_row(p.haloRecv + 2 * Np, rec8);
+                    } else {
+                        hq = ld_row(qin, o8);
+                        huq = ld_row(qin + plane, o8);
+                        hvq = ld_row(qin + 2 * plane, o8);
+                    }
                     double nM = 0.0, nP = 0.0;
                     if constexpr (TRACER) {
                         nM = ld_row(qin + 3 * plane + m * ld, k8);
@@ -523,6 +540,13 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
 
         // ---- stage update / output, one field at a time
         if (live) {
+            int sendRec[3] = {-1, -1, -1};
+            if constexpr (HALO) {
+                const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
+                sendRec[0] = p.haloSendOf[b3];
+                sendRec[1] = p.haloSendOf[b3 + 1];
+                sendRec[2] = p.haloSendOf[b3 + 2];
+            }
 #pragma unroll
             for (int c = 0; c < NFLD; ++c) {
                 const long long fo = static_cast<long long>(c) * plane;
@@ -552,8 +576,15 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
                                 st_row(p.rhs + fo + i * ld, k8, R);
                             } else if constexpr (MODE == MODE_LSERK) {
                                 const double n1 = p.ca * oldv[r][reg] + p.cc * R;
+                                const double qn = qv[r][reg] + p.cb * n1;
                                 st_row(p.res + fo + i * ld, k8, n1);
-                                st_row(p.qout + fo + i * ld, k8, qv[r][reg] + p.cb * n1);
+                                st_row(p.qout + fo + i * ld, k8, qn);
+                                if constexpr (HALO) {
+#pragma unroll
+                                    for (int sr = 0; sr < 3; ++sr)
+                                        if (sendRec[sr] >= 0)
+                                            p.haloSend[static_cast<size_t>(sendRec[sr]) * p.haloRows + c * Np + i] = qn;
+                                }
                             } else {
                                 const double val = p.ca * oldv[r][reg] + p.cb * qv[r][reg] + p.cc * R;
                                 double sp = p.sponge;

@@ -194,6 +194,17 @@ hipError_t stageMfmaHalo(const StageParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// the same for the face-by-face matrix-core kernel (the boundary strip's kernel at N >= 5)
+hipError_t stageMfma2Halo(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const size_t ldsBytes = sizeof(double) * MfmaOps2<kN>::DOUBLES;
+    const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
+    const unsigned perCu = static_cast<unsigned>(std::min<size_t>(BDG_MFMA2_WAVES, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
+    const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
+    hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE_LSERK, 0, false, true>), dim3(grid), dim3(256), ldsBytes, stream, p, PhysParams{});
+    return hipGetLastError();
+}
+
 hipError_t stageMfma(int mode, const StageParams& p, hipStream_t stream) {
     switch (mode) {
     case MODE_RHS: return launchMfma<MODE_RHS>(p, stream);
@@ -336,7 +347,7 @@ int fmaskOf(int f, int n) { return Elem<kN>::fmask(f, n); }
 const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
-                                      MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
+                                      MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, &stageMfma2Halo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
                                       &stageMfma2, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;

@@ -135,16 +135,16 @@ def test_native_rccl_single_rank(tmp_path):
 
 @pytest.mark.parametrize("order,world,shape,halo_kernels", [
     (4, 2, (48, 36), False), (4, 3, (48, 36), False), (4, 5, (40, 40), False), (2, 8, (64, 32), False),
-    (6, 4, (24, 20), False), (8, 2, (12, 10), False), (4, 4, (48, 36), True), (3, 3, (40, 30), True)])
+    (6, 4, (24, 20), False), (8, 2, (12, 10), False), (5, 3, (30, 24), False), (4, 4, (48, 36), True),
+    (3, 3, (40, 30), True), (6, 3, (24, 20), True)])
 def test_overlapped_two_chain_schedule_matches_single_domain(order, world, shape, halo_kernels, monkeypatch):
     """The production stage schedule (interior elements on the compute stream, pack / exchange /
     unpack / boundary elements on the exchange stream, meeting one stage later through alternating
     events) with every part of the split on this one GPU and device-to-device copies as the
     transport: after 23 stages (not a multiple of 5, odd) the assembled state must equal the
     single-domain run bit for bit -- any missing dependency between the chains shows up as a
-    difference. At N <= 4 the boundary kernel does the halo staging itself (reads the received records,
-    writes the send records); halo_kernels=True (BDG_SW2D_HALO_KERNELS=1) keeps the separate pack / unpack
-    kernels that higher orders use."""
+    difference. The boundary kernel does the halo staging itself (reads the received records, writes the
+    send records); halo_kernels=True (BDG_SW2D_HALO_KERNELS=1) keeps the separate pack / unpack kernels."""
     if halo_kernels:
         monkeypatch.setenv("BDG_SW2D_HALO_KERNELS", "1")
     import blitzdg_amd.pyblitzdg as dg
