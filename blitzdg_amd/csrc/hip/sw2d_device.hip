@@ -1643,11 +1643,14 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         s->commWorld = world;
         s->peers = peers;
         hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
-        // These four events only order kernels of the two streams of THIS device against each other (the
-        // kernels' own end-of-kernel release is device-wide); the system-scope fence of a default event record
-        // is not needed for that and costs 2-3 us per stage.
+        // These four events only order kernels of the two streams of THIS device against each other. Default
+        // record semantics (system-scope fence) until a run between distinct GPUs has shown bit-exact parity
+        // without it; BDG_SW2D_EVENT_NOFENCE=1 drops the fence (2-3 us per stage; tests/test_dist_gpu.py
+        // compares both settings bit for bit on the loop-back RCCL path).
+        const char* nofence = std::getenv("BDG_SW2D_EVENT_NOFENCE");
+        const unsigned evFlags = hipEventDisableTiming | ((nofence && nofence[0] == '1') ? hipEventDisableSystemFence : 0u);
         for (hipEvent_t* e : {&s->evA[0], &s->evA[1], &s->evB[0], &s->evB[1]})
-            hipCheck(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate");
+            hipCheck(hipEventCreateWithFlags(e, evFlags), "hipEventCreate");
         const size_t rows = static_cast<size_t>(s->nf) * s->Np;
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);

@@ -125,32 +125,62 @@ def build_local_mesh(plan):
     return mesh
 
 
-def file_rendezvous(rank, world, make_id, timeout=300.0):
-    """Hands rank 0's 128-byte RCCL id to every rank of a single-node job through a file in
-    /tmp. The name is unique per launch: all ranks are children of one launcher process (its
-    pid) and share MASTER_PORT. Rank 0 removes the file once every rank has joined
-    (see NativeDistributedSw2d)."""
+def _launcher_start_time(pid):
+    """Wall-clock start of process `pid` (the launcher all ranks are children of), or 0.0."""
     import os
+    try:
+        with open(f"/proc/{pid}/stat") as f:
+            ticks = int(f.read().rsplit(")", 1)[1].split()[19])
+        with open("/proc/stat") as f:
+            btime = next(int(ln.split()[1]) for ln in f if ln.startswith("btime"))
+        return btime + ticks / os.sysconf("SC_CLK_TCK")
+    except (OSError, ValueError, StopIteration, IndexError):
+        return 0.0
+
+
+def file_rendezvous(rank, world, make_id, timeout=300.0):
+    """Hands rank 0's 128-byte RCCL id to every rank of a single-node job through a file in a
+    private (0700, owned by this user) directory under /tmp. The name is unique per launch: all ranks
+    are children of one launcher process (its pid) and share MASTER_PORT and, where the launcher sets
+    one, a nonce (bench.py's own launcher: BDG_LAUNCH_NONCE; torchrun: TORCHELASTIC_RUN_ID). Rank 0
+    unlinks whatever an earlier, crashed launch left under that name and creates the file with
+    O_EXCL, mode 0600; the record carries rank 0's clock, and a reader only accepts a record written
+    after its launcher started (a recycled launcher pid cannot match a stale record). Rank 0 removes
+    the file once every rank has joined (see NativeDistributedSw2d)."""
+    import os
+    import struct
     import time
-    path = f"/tmp/bdg_rccl_id_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{world}"
+    base = os.path.join(os.environ.get("BDG_RENDEZVOUS_DIR", "/tmp"), f"bdg_rccl_{os.getuid()}")
+    os.makedirs(base, mode=0o700, exist_ok=True)
+    st = os.lstat(base)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077) or not os.path.isdir(base) or os.path.islink(base):
+        raise RuntimeError(f"{base} is not a private directory of this user; refusing to exchange the RCCL id there")
+    nonce = os.environ.get("BDG_LAUNCH_NONCE") or os.environ.get("TORCHELASTIC_RUN_ID", "none")
+    path = os.path.join(base, f"id_{os.getppid()}_{os.environ.get('MASTER_PORT', '0')}_{world}_{nonce}")
     if rank == 0:
         uid = make_id()
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
         tmp = f"{path}.{os.getpid()}.tmp"
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)  # atomic: readers never see a partial id
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, "wb") as f:
+            f.write(struct.pack("<d", time.time()) + uid)
+        os.replace(tmp, path)  # atomic: readers never see a partial record
         return uid, path
+    not_before = _launcher_start_time(os.getppid()) - 1.0
     deadline = time.time() + timeout
     while time.time() < deadline:
         try:
             with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == 128:
-                return uid, path
+                rec = f.read()
+            if len(rec) == 136 and struct.unpack("<d", rec[:8])[0] >= not_before:
+                return rec[8:], path
         except FileNotFoundError:
             pass
         time.sleep(0.02)
-    raise TimeoutError(f"rank {rank}: no RCCL id at {path} after {timeout} s")
+    raise TimeoutError(f"rank {rank}: no fresh RCCL id at {path} after {timeout} s")
 
 
 class NativeDistributedSw2d:

@@ -30,4 +30,12 @@ public:
     void solve(const real_matrix_type& A, real_vector_type& eigenvalues, real_matrix_type& eigenvectors) const;
 };
 
+class DenseCholeskyFactorizer {
+public:
+    /// R = upper triangular factor with A = R^T R (the reference calls dpotrf_('U'),
+    /// src/DenseCholeskyFactorizer.cpp:23-53, and zeroes the strict lower triangle); throws
+    /// std::runtime_error when a leading minor is not positive definite.
+    void computeCholesky(const real_matrix_type& A, real_matrix_type& R) const;
+};
+
 } // namespace blitzdg

@@ -294,6 +294,23 @@ def test_bench_two_ranks_through_the_mock_transport(mock_rccl):
     assert abs(d["config"]["mass_relative_drift"]) < 1e-13
 
 
+def test_bench_plain_gpus_flag_starts_its_own_ranks(mock_rccl):
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: the parent starts the two rank processes itself
+    (LOCAL_RANK 1 folded onto the only device, stand-in transport) and relays rank 0's one line with n_gpus = 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4",
+                          "--cells", "60x40"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0", **mock_rccl))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["config"]["elements"] == 4800
+    assert d["config"]["rank0_partition"]["ghost"] > 0 and abs(d["config"]["mass_relative_drift"]) < 1e-13
+
+
 def test_bench_under_torch_distributed_run_exact_driver_command(mock_rccl):
     """The driver's own N > 1 command line: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
     --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W (here N = 2, LOCAL_RANK 1
