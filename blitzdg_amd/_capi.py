@@ -24,6 +24,10 @@ BDG_SW2D_KEEP_ORDER = 4
 (TRI_R, TRI_S, TRI_X, TRI_Y, TRI_V, TRI_VINV, TRI_DR, TRI_DS, TRI_DRW, TRI_DSW, TRI_LIFT, TRI_FILTER,
  TRI_J, TRI_RX, TRI_RY, TRI_SX, TRI_SY, TRI_NX, TRI_NY, TRI_FSCALE, TRI_FMASK, TRI_FX, TRI_FY,
  TRI_VMAPM, TRI_VMAPP, TRI_MAPP, TRI_VMAPB, TRI_MAPB, TRI_GATHER, TRI_SCATTER) = range(30)
+(GAUSS_NX, GAUSS_NY, GAUSS_SJ, GAUSS_J, GAUSS_RX, GAUSS_RY, GAUSS_SX, GAUSS_SY, GAUSS_X, GAUSS_Y, GAUSS_W,
+ GAUSS_INTERP, GAUSS_MAPM, GAUSS_MAPP) = range(14)
+(CUB_R, CUB_S, CUB_WEIGHTS, CUB_V, CUB_RX, CUB_RY, CUB_SX, CUB_SY, CUB_J, CUB_DR, CUB_DS, CUB_MM, CUB_MMCHOL,
+ CUB_X, CUB_Y, CUB_W) = range(16)
 (N1D_R, N1D_X, N1D_V, N1D_VINV, N1D_DR, N1D_LIFT, N1D_J, N1D_RX, N1D_NX, N1D_FMASK, N1D_FX,
  N1D_FSCALE, N1D_ETOV, N1D_ETOE, N1D_ETOF, N1D_VMAPM, N1D_VMAPP) = range(17)
 
@@ -100,6 +104,18 @@ _SIGNATURES = {
     "bdg_trinodes_split_operators": (c_int, [_P, _P, _P]),
     "bdg_trinodes_split_elements": (c_int, [_P, _P, _P, _P, _P]),
     "bdg_trinodes_write_vtu": (c_int, [_P, c_char_p, _P, c_char_p]),
+    "bdg_trinodes_build_gauss_face_nodes": (c_int, [_P, c_int, POINTER(_P)]),
+    "bdg_gaussctx_destroy": (None, [_P]),
+    "bdg_gaussctx_ngauss": (c_int, [_P]),
+    "bdg_gaussctx_table": (c_int, [_P, c_int, POINTER(Table)]),
+    "bdg_gaussctx_bcmap_num_tags": (c_int, [_P]),
+    "bdg_gaussctx_bcmap_tags": (c_int, [_P, POINTER(c_int), c_int]),
+    "bdg_gaussctx_bcmap_nodes": (c_int, [_P, c_int, POINTER(POINTER(c_int)), POINTER(c_int)]),
+    "bdg_trinodes_build_cubature_volume_mesh": (c_int, [_P, c_int, POINTER(_P)]),
+    "bdg_cubctx_destroy": (None, [_P]),
+    "bdg_cubctx_num_points": (c_int, [_P]),
+    "bdg_cubctx_order": (c_int, [_P]),
+    "bdg_cubctx_table": (c_int, [_P, c_int, POINTER(Table)]),
     "bdg_nodes1d_create": (c_int, [c_int, c_int, c_double, c_double, POINTER(_P)]),
     "bdg_nodes1d_destroy": (None, [_P]),
     "bdg_nodes1d_build_nodes": (c_int, [_P]),

@@ -350,6 +350,107 @@ int bdg_trinodes_bcmap_nodes(const bdg_trinodes* nodes, int tag, const int** out
     });
 }
 
+// ------------------------------------------------------------------ Gauss face / cubature contexts
+
+int bdg_trinodes_build_gauss_face_nodes(bdg_trinodes* nodes, int NGauss, bdg_gaussctx** out) {
+    return guard([&] {
+        if (!nodes || !out) throw bdg_detail::arg_error("bdg_trinodes_build_gauss_face_nodes: NULL argument");
+        if (NGauss < 1) throw bdg_detail::arg_error("bdg_trinodes_build_gauss_face_nodes: NGauss must be >= 1");
+        *out = new bdg_gaussctx{nodes->prov.buildGaussFaceNodes(NGauss)};
+    });
+}
+
+void bdg_gaussctx_destroy(bdg_gaussctx* ctx) { delete ctx; }
+int bdg_gaussctx_ngauss(const bdg_gaussctx* ctx) { return ctx ? ctx->ctx.NGauss() : -1; }
+
+int bdg_gaussctx_table(const bdg_gaussctx* ctx, int which, bdg_table* out) {
+    return guard([&] {
+        if (!ctx || !out) throw bdg_detail::arg_error("bdg_gaussctx_table: NULL argument");
+        const GaussFaceContext2D& g = ctx->ctx;
+        switch (which) {
+        case BDG_GAUSS_NX: view(out, g.nx()); break;
+        case BDG_GAUSS_NY: view(out, g.ny()); break;
+        case BDG_GAUSS_SJ: view(out, g.sJ()); break;
+        case BDG_GAUSS_J: view(out, g.Jac()); break;
+        case BDG_GAUSS_RX: view(out, g.rx()); break;
+        case BDG_GAUSS_RY: view(out, g.ry()); break;
+        case BDG_GAUSS_SX: view(out, g.sx()); break;
+        case BDG_GAUSS_SY: view(out, g.sy()); break;
+        case BDG_GAUSS_X: view(out, g.x()); break;
+        case BDG_GAUSS_Y: view(out, g.y()); break;
+        case BDG_GAUSS_W: view(out, g.W()); break;
+        case BDG_GAUSS_INTERP: view(out, g.Interp()); break;
+        case BDG_GAUSS_MAPM: view(out, g.mapM()); break;
+        case BDG_GAUSS_MAPP: view(out, g.mapP()); break;
+        default: throw bdg_detail::arg_error("bdg_gaussctx_table: unknown table id");
+        }
+    });
+}
+
+int bdg_gaussctx_bcmap_num_tags(const bdg_gaussctx* ctx) { return ctx ? static_cast<int>(ctx->ctx.bcMap().size()) : -1; }
+
+int bdg_gaussctx_bcmap_tags(const bdg_gaussctx* ctx, int* tags, int capacity) {
+    return guard([&] {
+        if (!ctx || (!tags && capacity > 0)) throw bdg_detail::arg_error("bdg_gaussctx_bcmap_tags: NULL argument");
+        std::vector<int> keys;
+        for (const auto& kv : ctx->ctx.bcMap()) keys.push_back(kv.first);
+        std::sort(keys.begin(), keys.end());
+        if (static_cast<int>(keys.size()) > capacity) throw bdg_detail::arg_error("bdg_gaussctx_bcmap_tags: capacity too small");
+        std::copy(keys.begin(), keys.end(), tags);
+    });
+}
+
+int bdg_gaussctx_bcmap_nodes(const bdg_gaussctx* ctx, int tag, const int** out, int* count) {
+    return guard([&] {
+        if (!ctx || !out || !count) throw bdg_detail::arg_error("bdg_gaussctx_bcmap_nodes: NULL argument");
+        const auto it = ctx->ctx.bcMap().find(tag);
+        if (it == ctx->ctx.bcMap().end()) { *out = nullptr; *count = 0; return; }
+        *out = it->second.data();
+        *count = static_cast<int>(it->second.size());
+    });
+}
+
+int bdg_trinodes_build_cubature_volume_mesh(bdg_trinodes* nodes, int NCubature, bdg_cubctx** out) {
+    return guard([&] {
+        if (!nodes || !out) throw bdg_detail::arg_error("bdg_trinodes_build_cubature_volume_mesh: NULL argument");
+        if (NCubature < 1) throw bdg_detail::arg_error("bdg_trinodes_build_cubature_volume_mesh: NCubature must be >= 1");
+        *out = new bdg_cubctx{nodes->prov.buildCubatureVolumeMesh(NCubature)};
+    });
+}
+
+void bdg_cubctx_destroy(bdg_cubctx* ctx) { delete ctx; }
+int bdg_cubctx_num_points(const bdg_cubctx* ctx) { return ctx ? ctx->ctx.NumCubaturePoints() : -1; }
+int bdg_cubctx_order(const bdg_cubctx* ctx) { return ctx ? ctx->ctx.NCubature() : -1; }
+
+int bdg_cubctx_table(const bdg_cubctx* ctx, int which, bdg_table* out) {
+    return guard([&] {
+        if (!ctx || !out) throw bdg_detail::arg_error("bdg_cubctx_table: NULL argument");
+        const CubatureContext2D& c = ctx->ctx;
+        auto view3 = [&](const real_tensor3_type& t) {
+            *out = {t.data(), t.length(0) * t.length(1), t.length(2), BDG_F64};
+        };
+        switch (which) {
+        case BDG_CUB_R: view(out, c.r()); break;
+        case BDG_CUB_S: view(out, c.s()); break;
+        case BDG_CUB_WEIGHTS: view(out, c.w()); break;
+        case BDG_CUB_V: view(out, c.V()); break;
+        case BDG_CUB_RX: view(out, c.rx()); break;
+        case BDG_CUB_RY: view(out, c.ry()); break;
+        case BDG_CUB_SX: view(out, c.sx()); break;
+        case BDG_CUB_SY: view(out, c.sy()); break;
+        case BDG_CUB_J: view(out, c.Jac()); break;
+        case BDG_CUB_DR: view(out, c.Dr()); break;
+        case BDG_CUB_DS: view(out, c.Ds()); break;
+        case BDG_CUB_MM: view3(c.MM()); break;
+        case BDG_CUB_MMCHOL: view3(c.MMChol()); break;
+        case BDG_CUB_X: view(out, c.x()); break;
+        case BDG_CUB_Y: view(out, c.y()); break;
+        case BDG_CUB_W: view(out, c.W()); break;
+        default: throw bdg_detail::arg_error("bdg_cubctx_table: unknown table id");
+        }
+    });
+}
+
 // ------------------------------------------------------------------ 1-D nodes
 
 int bdg_nodes1d_create(int order, int K, double xmin, double xmax, bdg_nodes1d** out) {

@@ -18,6 +18,14 @@ struct bdg_trinodes {
     bool hasFilter = false;
 };
 
+struct bdg_gaussctx {
+    blitzdg::GaussFaceContext2D ctx;
+};
+
+struct bdg_cubctx {
+    blitzdg::CubatureContext2D ctx;
+};
+
 struct bdg_nodes1d {
     blitzdg::Nodes1DProvisioner prov;
 };

@@ -149,4 +149,27 @@ void EigenSolver::solve(const real_matrix_type& A, real_vector_type& eigenvalues
     }
 }
 
+void DenseCholeskyFactorizer::computeCholesky(const real_matrix_type& A, real_matrix_type& R) const {
+    const index_type n = A.rows();
+    if (A.cols() != n) throw std::runtime_error("computeCholesky: matrix is not square");
+    if (R.rows() != n || R.cols() != n) R.resize(n, n);
+    else R.fill(0.0);
+    // row-oriented (Cholesky-Banachiewicz on the upper factor): R(i,i) = sqrt(A(i,i) - sum_k R(k,i)^2),
+    // R(i,j) = (A(i,j) - sum_k R(k,i) R(k,j)) / R(i,i) for j > i
+    for (index_type i = 0; i < n; ++i) {
+        real_type d = A(i, i);
+        for (index_type k = 0; k < i; ++k) d -= R(k, i) * R(k, i);
+        if (!(d > 0.0))
+            throw std::runtime_error("The leading minor of order " + std::to_string(i + 1) +
+                                     " is not positive definite. The Cholesky factorization could not be completed.");
+        const real_type rii = std::sqrt(d);
+        R(i, i) = rii;
+        for (index_type j = i + 1; j < n; ++j) {
+            real_type v = A(i, j);
+            for (index_type k = 0; k < i; ++k) v -= R(k, i) * R(k, j);
+            R(i, j) = v / rii;
+        }
+    }
+}
+
 } // namespace blitzdg

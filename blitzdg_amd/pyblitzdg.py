@@ -5,7 +5,8 @@ Same class, method and property names as the reference's boost::python module
 ``MeshManager``, ``TriangleNodesProvisioner`` (+ ``dgContext()`` -> ``DGContext2D``),
 ``Nodes1DProvisioner``, ``LSERK4``, ``BCType``. As in the reference every property
 access returns a FRESH C-order ndarray (float64 / int32). Objects outside the hot
-path (quads, Gauss/cubature contexts, VTK, Poisson) are not provided.
+path (quads, Poisson) are not provided. ``GaussFaceContext2D`` / ``CubatureContext2D`` (the curved,
+over-integrated RHS's tables) come from ``buildGaussFaceNodes`` / ``buildCubatureVolumeMesh``.
 """
 import numpy as np
 
@@ -141,6 +142,85 @@ class DGContext2D:
         return self._nodes._bcmap()
 
 
+class GaussFaceContext2D:
+    """Gauss quadrature mesh on the element faces. reference: include/GaussFaceContext2D.hpp:68-104;
+    python names at pyblitzdg.cpp:124-140. Owns its tables (a snapshot of the provisioner's coordinates
+    at build time); every property access returns a fresh ndarray."""
+
+    _TABLES = {"nx": C.GAUSS_NX, "ny": C.GAUSS_NY, "sJ": C.GAUSS_SJ, "J": C.GAUSS_J, "rx": C.GAUSS_RX,
+               "ry": C.GAUSS_RY, "sx": C.GAUSS_SX, "sy": C.GAUSS_SY, "x": C.GAUSS_X, "y": C.GAUSS_Y,
+               "W": C.GAUSS_W, "Interp": C.GAUSS_INTERP, "mapM": C.GAUSS_MAPM, "mapP": C.GAUSS_MAPP}
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.bdg_gaussctx_destroy(h)
+
+    def __getattr__(self, name):
+        which = GaussFaceContext2D._TABLES.get(name)
+        if which is None:
+            raise AttributeError(name)
+        t = C.Table()
+        check(lib.bdg_gaussctx_table(self._h, which, byref(t)))
+        return C.table_to_numpy(t)
+
+    @property
+    def NGauss(self):
+        return lib.bdg_gaussctx_ngauss(self._h)
+
+    @property
+    def BCmap(self):
+        n = lib.bdg_gaussctx_bcmap_num_tags(self._h)
+        tags = (c_int * max(n, 1))()
+        check(lib.bdg_gaussctx_bcmap_tags(self._h, tags, n))
+        out = {}
+        for i in range(n):
+            p, cnt = C.POINTER(c_int)(), c_int()
+            check(lib.bdg_gaussctx_bcmap_nodes(self._h, tags[i], byref(p), byref(cnt)))
+            out[int(tags[i])] = np.ctypeslib.as_array(p, shape=(cnt.value,)).tolist() if cnt.value else []
+        return out
+
+
+class CubatureContext2D:
+    """Volume cubature mesh of the elements. reference: include/CubatureContext2D.hpp:75-118; python
+    names at pyblitzdg.cpp:142-158. MM / MMChol are (Np, Np, K) as in the reference."""
+
+    _TABLES = {"r": C.CUB_R, "s": C.CUB_S, "w": C.CUB_WEIGHTS, "V": C.CUB_V, "rx": C.CUB_RX, "ry": C.CUB_RY,
+               "sx": C.CUB_SX, "sy": C.CUB_SY, "J": C.CUB_J, "Dr": C.CUB_DR, "Ds": C.CUB_DS, "MM": C.CUB_MM,
+               "MMChol": C.CUB_MMCHOL, "x": C.CUB_X, "y": C.CUB_Y, "W": C.CUB_W}
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.bdg_cubctx_destroy(h)
+
+    def __getattr__(self, name):
+        which = CubatureContext2D._TABLES.get(name)
+        if which is None:
+            raise AttributeError(name)
+        t = C.Table()
+        check(lib.bdg_cubctx_table(self._h, which, byref(t)))
+        arr = C.table_to_numpy(t)
+        if name in ("MM", "MMChol"):
+            n = int(round(np.sqrt(arr.shape[0])))
+            arr = arr.reshape(n, n, arr.shape[1])
+        return arr
+
+    @property
+    def NCubature(self):
+        return lib.bdg_cubctx_order(self._h)
+
+    @property
+    def NumCubaturePoints(self):
+        return lib.bdg_cubctx_num_points(self._h)
+
+
 class TriangleNodesProvisioner:
     """reference: include/TriangleNodesProvisioner.hpp:32-427; python names at pyblitzdg.cpp:114-119"""
 
@@ -201,6 +281,19 @@ class TriangleNodesProvisioner:
         _, Np, _, K = self._dims()
         xa, ya = C.as_f64(x, (Np, K), "x"), C.as_f64(y, (Np, K), "y")
         check(lib.bdg_trinodes_set_coordinates(self._h, C.ptr(xa), C.ptr(ya)))
+
+    def buildGaussFaceNodes(self, NGauss):
+        """reference src/TriangleNodesProvisioner.cpp:207-381"""
+        h = c_void_p()
+        check(lib.bdg_trinodes_build_gauss_face_nodes(self._h, int(NGauss), byref(h)))
+        return GaussFaceContext2D(h)
+
+    def buildCubatureVolumeMesh(self, NCubature):
+        """reference src/TriangleNodesProvisioner.cpp:81-205 (also recomputes the nodal J, rx, ry, sx, sy)"""
+        h = c_void_p()
+        check(lib.bdg_trinodes_build_cubature_volume_mesh(self._h, int(NCubature), byref(h)))
+        self._tables_version = getattr(self, "_tables_version", 0) + 1
+        return CubatureContext2D(h)
 
     def dgContext(self):
         return DGContext2D(self)

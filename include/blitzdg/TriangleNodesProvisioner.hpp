@@ -7,8 +7,10 @@
 // (buildNodes -> buildLift -> buildPhysicalGrid -> buildMaps). The object is
 // movable, not copyable, and owns its tables; the RHS evaluators only read them.
 #pragma once
+#include "CubatureContext2D.hpp"
 #include "DGContext2D.hpp"
 #include "DenseLinAlg.hpp"
+#include "GaussFaceContext2D.hpp"
 #include "JacobiBuilders.hpp"
 #include "MeshManager.hpp"
 #include "Types.hpp"
@@ -71,6 +73,12 @@ public:
     /// Overwrites the physical node coordinates (curved meshes); geometry is NOT
     /// rebuilt, as in the reference's setCoordinates_numpy (:1266-1272).
     void setCoordinates(const real_type* x, const real_type* y);
+    /// Gauss-Legendre quadrature mesh of order NGauss on every face (reference
+    /// src/TriangleNodesProvisioner.cpp:207-381), from the CURRENT node coordinates.
+    GaussFaceContext2D buildGaussFaceNodes(index_type NGauss);
+    /// Volume cubature mesh exact to degree NCubature (reference :81-205); as there, the nodal J, rx,
+    /// ry, sx, sy of this provisioner are recomputed from the current node coordinates as a side effect.
+    CubatureContext2D buildCubatureVolumeMesh(index_type NCubature);
 
     // ---- accessors
     const real_matrix_type& get_xGrid() const { return xGrid; }

@@ -44,6 +44,8 @@ extern "C" {
 typedef struct bdg_mesh bdg_mesh;
 typedef struct bdg_trinodes bdg_trinodes;
 typedef struct bdg_nodes1d bdg_nodes1d;
+typedef struct bdg_gaussctx bdg_gaussctx;
+typedef struct bdg_cubctx bdg_cubctx;
 typedef struct bdg_sw2d bdg_sw2d;
 
 const char* bdg_last_error(void);
@@ -119,6 +121,37 @@ int bdg_trinodes_split_elements(const bdg_trinodes* nodes, const double* field, 
                                 double* fieldnew);
 int bdg_trinodes_write_vtu(const bdg_trinodes* nodes, const char* path, const double* field,
                            const char* field_name);
+
+/* ---------------------------------------------------------------- GaussFaceContext2D / CubatureContext2D
+ * reference: TriangleNodesProvisioner::buildGaussFaceNodes (src/TriangleNodesProvisioner.cpp:207-381,
+ * include/GaussFaceContext2D.hpp:68-84) and ::buildCubatureVolumeMesh (:81-205,
+ * include/CubatureContext2D.hpp:75-96); python names at src/pyblitzdg/pyblitzdg.cpp:116-117, 124-158.
+ * The contexts own their tables (built from the provisioner's CURRENT coordinates) and outlive it.
+ * Gauss tables are (3*NGauss, K), Interp (3*NGauss, Np), mapM/mapP (3*NGauss*K) flat ids g + 3*NGauss*k.
+ * Cubature tables are (Ncub, K), V/Dr/Ds (Ncub, Np), r/s/w (Ncub); MM and MMChol are the reference's
+ * (Np, Np, K) tensors viewed as (Np*Np, K). build_cubature_volume_mesh also recomputes the provisioner's
+ * nodal J, rx, ry, sx, sy from its current coordinates, as the reference does. The cubature rule is a
+ * computed conical-product rule of the requested degree (include/blitzdg/TriangleCubatureRules.hpp). */
+enum {
+    BDG_GAUSS_NX = 0, BDG_GAUSS_NY, BDG_GAUSS_SJ, BDG_GAUSS_J, BDG_GAUSS_RX, BDG_GAUSS_RY, BDG_GAUSS_SX,
+    BDG_GAUSS_SY, BDG_GAUSS_X, BDG_GAUSS_Y, BDG_GAUSS_W, BDG_GAUSS_INTERP, BDG_GAUSS_MAPM, BDG_GAUSS_MAPP
+};
+enum {
+    BDG_CUB_R = 0, BDG_CUB_S, BDG_CUB_WEIGHTS, BDG_CUB_V, BDG_CUB_RX, BDG_CUB_RY, BDG_CUB_SX, BDG_CUB_SY,
+    BDG_CUB_J, BDG_CUB_DR, BDG_CUB_DS, BDG_CUB_MM, BDG_CUB_MMCHOL, BDG_CUB_X, BDG_CUB_Y, BDG_CUB_W
+};
+int bdg_trinodes_build_gauss_face_nodes(bdg_trinodes* nodes, int NGauss, bdg_gaussctx** out);
+void bdg_gaussctx_destroy(bdg_gaussctx* ctx);
+int bdg_gaussctx_ngauss(const bdg_gaussctx* ctx);
+int bdg_gaussctx_table(const bdg_gaussctx* ctx, int which, bdg_table* out);
+int bdg_gaussctx_bcmap_num_tags(const bdg_gaussctx* ctx);
+int bdg_gaussctx_bcmap_tags(const bdg_gaussctx* ctx, int* tags, int capacity);
+int bdg_gaussctx_bcmap_nodes(const bdg_gaussctx* ctx, int tag, const int** nodes_out, int* count);
+int bdg_trinodes_build_cubature_volume_mesh(bdg_trinodes* nodes, int NCubature, bdg_cubctx** out);
+void bdg_cubctx_destroy(bdg_cubctx* ctx);
+int bdg_cubctx_num_points(const bdg_cubctx* ctx);
+int bdg_cubctx_order(const bdg_cubctx* ctx);
+int bdg_cubctx_table(const bdg_cubctx* ctx, int which, bdg_table* out);
 
 /* ---------------------------------------------------------------- Nodes1DProvisioner
  * reference: include/Nodes1DProvisioner.hpp:25-302 */

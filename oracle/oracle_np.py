@@ -219,3 +219,71 @@ def step_ssprk2_b(h, hu, hv, H, Hx, Hy, g, f, CD, time, dt, nsteps, t, mapO=(), 
         hv = hv / (1.0 + sp * hv * hv)
         time += dt
     return h, hu, hv, time
+
+
+# ------------------------------------------------------------------------------------------------
+# Curved / over-integrated RHS: the reference's swhelpers.rhs.sw2dComputeRHS_curved
+# (swhelpers/rhs.py:6-176). Pinned bit for bit by tests/golden/sw2d_rhs_curved_*.npz, which hold the
+# output of the reference function itself on tables built by this repository's
+# buildGaussFaceNodes / buildCubatureVolumeMesh (tests/golden/make_golden.py).
+
+def sw2d_rhs_curved(h, hu, hv, hN, zx, zy, g, f, CD, t):
+    """t: mapping with the tables the reference function reads from its context arguments --
+    cubV cubDr cubDs (Ncub, Np); cubW cubrx cubry cubsx cubsy (Ncub, K); gInterp (3NG, Np); gW gnx gny
+    (3NG, K); gmapM gmapP gmapW (flat Gauss ids g + 3NG*k); V (Np, Np); J (Np, K); MMChol (Np, Np, K);
+    curvedEls. Same operations in the same order as rhs.py:6-176 (cub_zx, cub_zy, cub_H and the Gauss
+    trace of H are formed there but never used)."""
+    from scipy.linalg import solve_triangular
+    V_, Dr_, Ds_ = t["cubV"], t["cubDr"], t["cubDs"]
+    q = (h, hu, hv, hN)
+    cq = [np.dot(V_, a) for a in q]                                                    # rhs.py:8-11
+    F, G = fluxes(cq[0], cq[1], cq[2], cq[3], g)                                        # rhs.py:18
+    DrT, DsT = np.transpose(Dr_), np.transpose(Ds_)
+    W, rx, ry, sx, sy = t["cubW"], t["cubrx"], t["cubry"], t["cubsx"], t["cubsy"]
+    MM = []
+    for c in range(4):                                                                  # rhs.py:23-49
+        tmpr = W * (rx * F[c] + ry * G[c])
+        tmps = W * (sx * F[c] + sy * G[c])
+        MM.append(np.dot(DrT, tmpr) + np.dot(DsT, tmps))
+    nx, ny = t["gnx"], t["gny"]
+    mapW = np.asarray(t["gmapW"], dtype=np.int64)
+    gmapM, gmapP = np.asarray(t["gmapM"]), np.asarray(t["gmapP"])
+    nxW, nyW = nx.flatten("F")[mapW], ny.flatten("F")[mapW]                             # rhs.py:55-56
+    NG3, K = nx.shape
+    gq = [np.dot(t["gInterp"], a).flatten("F") for a in q]                              # rhs.py:61-75
+    hM, huM, hvM, hNM = (a[gmapM] for a in gq)
+    hP, huP, hvP, hNP = (a[gmapP] for a in gq)
+    uM, uP, vM, vP = huM / hM, huP / hP, hvM / hM, hvP / hP                             # rhs.py:81-85 (before the wall BC)
+    huP[mapW] = huM[mapW] - 2 * nxW * (huM[mapW] * nxW + hvM[mapW] * nyW)               # rhs.py:87-88
+    hvP[mapW] = hvM[mapW] - 2 * nyW * (huM[mapW] * nxW + hvM[mapW] * nyW)
+    FM, GM = fluxes(hM, huM, hvM, hNM, g)
+    FP, GP = fluxes(hP, huP, hvP, hNP, g)
+    spdM = np.sqrt(uM * uM + vM * vM) + np.sqrt(g * hM)
+    spdP = np.sqrt(uP * uP + vP * vP) + np.sqrt(g * hP)
+    spdMax = np.max(np.array([spdM, spdP]), axis=0)
+    Nfp = NG3 // 3
+    lam = np.reshape(spdMax, (Nfp, 3 * K), order="F")                                   # rhs.py:102-104
+    spdMax = np.reshape(np.outer(np.ones((Nfp, 1)), np.max(lam, axis=0)), (NG3, K), order="F")
+    shp = lambda a: np.reshape(a, (NG3, K), order="F")  # noqa: E731
+    dq = [shp(a - b) for a, b in ((hM, hP), (huM, huP), (hvM, hvP), (hNM, hNP))]
+    interpT = np.transpose(t["gInterp"])
+    gW = t["gW"]
+    for c in range(4):                                                                  # rhs.py:126-135
+        flux = 0.5 * ((shp(FM[c]) + shp(FP[c])) * nx + (shp(GM[c]) + shp(GP[c])) * ny + spdMax * dq[c])
+        MM[c] -= np.dot(interpT, gW * flux)
+    V = t["V"]
+    mmInv = np.dot(V, V.T)                                                              # rhs.py:150-156
+    J = t["J"]
+    out = [np.dot(mmInv, MM[c] / J) for c in range(4)]
+    chol = t["MMChol"]
+    for k in set(int(e) for e in np.asarray(t["curvedEls"]).reshape(-1)):               # rhs.py:157-162
+        U = chol[:, :, k]
+        for c in range(4):
+            out[c][:, k] = solve_triangular(U, solve_triangular(U, MM[c][:, k], trans="T"))
+    u, v = hu / h, hv / h                                                               # rhs.py:165-174
+    cdn = CD * np.hypot(u, v)
+    out[1] += f * hv - cdn * u
+    out[2] -= f * hu - cdn * v
+    out[1] -= g * h * zx
+    out[2] -= g * h * zy
+    return tuple(out)

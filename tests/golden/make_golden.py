@@ -13,7 +13,8 @@ Writes
                             parsed out of the literals in src/test/*.cpp:
                             vmapM/vmapP/vmapB/mapB/mapW (TriangleNodesProvisionerTests.cpp
                             :434-441), Dr/Ds (:310-330), Lift (:146-155), V (:219-228),
-                            equilateral nodes (:349-369), EToV/EToE/EToF/BCType/verts
+                            equilateral nodes (:349-369), cubature mass-matrix Cholesky factor
+                            (:526-536), EToV/EToE/EToF/BCType/verts
                             (MeshManagerTests.cpp:202-206), 1-D V/Dr/x/Lift/EToE/EToF/
                             vmapM/vmapP (Nodes1DProvisionerTests.cpp:52-247)
   sw2d_rhs_<case>.npz       inputs (tables built by THIS repo's host code + seeded
@@ -22,6 +23,10 @@ Writes
                             hN = 0, f = CD = 0, zx = zy = 0  (variant D == variant A up
                             to round-off)
   sw2d_rhs4_<case>.npz      the same function with tracer, Coriolis array, drag and bed slope
+  sw2d_rhs_curved_<case>.npz
+                            swhelpers.rhs.sw2dComputeRHS_curved (swhelpers/rhs.py:6-176) on deformed
+                            meshes; the Gauss-face and cubature contexts it reads are built by THIS
+                            repo's buildGaussFaceNodes / buildCubatureVolumeMesh and stored with it
   advec1d_rhs_N4_K100.npz   advec1dComputeRHS(u, c, nodes1d) of the reference SCRIPT advec1d.py:12-39
   sw2d_rhsC_<case>.npz      sw2dComputeRHS(h,hu,hv,hN,g,H,f,ctx) of the reference SCRIPT sw2d.py:37-146
                             ("variant C"), its two function definitions compiled on their own
@@ -59,6 +64,7 @@ def known_answers():
     out["tri_Ds"] = literals(tri, "expectedDs").reshape(10, 10)
     out["tri_Lift"] = literals(tri, "Lift_expected").reshape(10, 12)
     out["tri_V"] = literals(tri, "V_expected", 1).reshape(10, 10)
+    out["tri_cholExpected"] = literals(tri, "cholExpected").reshape(10, 10)   # :526-536, asserted to 6e-4 (:542)
     out["tri_eq_x"] = literals(tri, "expectedx")
     out["tri_eq_y"] = literals(tri, "expectedy")
     out["mesh_verts"] = literals(msh, "expectedVerts").reshape(29, 3)
@@ -154,6 +160,82 @@ def rhs4_case(name, mesh, order, g=9.81):
           f"{max(abs(a).max() for a in r):.6g}")
 
 
+def bump_deformation(x, y, centre, radius, amp):
+    """Smooth displacement with compact support (C^2 bump (1 - rho^2)^3 inside a disk, zero outside):
+    elements with every node outside the disk stay exactly straight-sided, faces between a deformed and
+    an undeformed element stay straight, and the two sides of every face keep the same curve."""
+    rho2 = ((x - centre[0]) ** 2 + (y - centre[1]) ** 2) / radius ** 2
+    b = np.where(rho2 < 1.0, (1.0 - rho2) ** 3, 0.0)
+    return x + amp[0] * b * np.cos(1.3 * y), y + amp[1] * b * np.sin(1.7 * x + 0.4)
+
+
+def curved_case(name, mesh, order, deform, flag="deformed", periodic_x=False, g=9.81 * 0.0025):
+    """Curved / over-integrated RHS: output of the reference's swhelpers.rhs.sw2dComputeRHS_curved
+    (swhelpers/rhs.py:6-176) with every context argument built by this repository: nodes moved by
+    `deform` + setCoordinates, gauss_ctx = buildGaussFaceNodes(2(N+1)), cub_ctx =
+    buildCubatureVolumeMesh(3(N+1)), J = xr*ys - xs*yr as the driver forms it (sw2d_curved.py:112-118).
+    flag: "deformed" -> curvedEls = the elements whose nodes moved; "half" -> every second one of them
+    (the rest take the standard mass matrix with their nodal, non-constant J, as the function allows).
+    periodic_x: the Gauss map gmapP of the x = xmin / x = xmax boundary faces is rewired to the
+    opposite side (what swhelpers.maps.makeMapsPeriodic does to the driver's maps)."""
+    import blitzdg_amd.pyblitzdg as dg
+    sys.path.insert(0, REF)
+    if not hasattr(np, "float"):
+        np.float = float
+    from swhelpers.rhs import sw2dComputeRHS_curved
+
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    ctx = nodes.dgContext()
+    x0, y0 = ctx.x, ctx.y
+    x, y = deform(x0, y0)
+    moved = np.where((np.abs(x - x0) + np.abs(y - y0)).max(axis=0) > 0)[0]
+    curvedEls = moved if flag == "deformed" else moved[::2]
+    nodes.setCoordinates(x, y)
+    Dr, Ds = ctx.Dr, ctx.Ds
+    J = np.dot(Dr, x) * np.dot(Ds, y) - np.dot(Ds, x) * np.dot(Dr, y)
+    gauss = nodes.buildGaussFaceNodes(2 * (order + 1))
+    cub = nodes.buildCubatureVolumeMesh(3 * (order + 1))
+    assert cub.J.min() > 0 and gauss.J.min() > 0, "deformation inverted an element"
+    gmapM, gmapP = gauss.mapM, gauss.mapP
+    gbc = gauss.BCmap
+    gmapW = np.array(gbc.get(3, []), dtype=np.int32)
+    if periodic_x:
+        gx, gy = gauss.x.flatten("F"), gauss.y.flatten("F")
+        left = [i for i in gmapW if abs(gx[i] - gx.min()) < 1e-9]
+        right = [i for i in gmapW if abs(gx[i] - gx.max()) < 1e-9]
+        for a, b in ((left, right), (right, left)):
+            for i in a:
+                j = min(b, key=lambda m: abs(gy[m] - gy[i]))
+                assert abs(gy[j] - gy[i]) < 1e-9
+                gmapP[i] = j
+        gmapW = np.array([i for i in gmapW if i not in set(left) | set(right)], dtype=np.int32)
+        gbc = dict(gbc)
+        gbc[3] = [int(i) for i in gmapW]
+    h, hu, hv = seeded_fields(x, y)
+    h = h - 9.0                      # depth 1..2: the free-surface hump matters against the mean depth
+    rng = np.random.default_rng(3)
+    hN = h * (0.5 + 0.3 * np.sin(2 * x) * np.cos(3 * y)) + 0.02 * rng.standard_normal(x.shape)
+    H = 1.0 - 0.05 * x + 0.02 * y * y
+    zx, zy = 0.05 + 0 * x, -0.04 * y
+    f, CD = 7.8825e-5 * 1e3, 2.5e-3 * (1.0 + 0.5 * np.cos(x))   # CD is a nodal array in the driver (sw2d_curved.py:176-192)
+    ref_ctx = types.SimpleNamespace(numLocalPoints=ctx.numLocalPoints, numElements=ctx.numElements, V=ctx.V)
+    ref_cub = types.SimpleNamespace(V=cub.V, Dr=cub.Dr, Ds=cub.Ds, W=cub.W, rx=cub.rx, ry=cub.ry, sx=cub.sx, sy=cub.sy,
+                                    MMChol=cub.MMChol)
+    ref_gauss = types.SimpleNamespace(nx=gauss.nx, ny=gauss.ny, BCmap=gbc, Interp=gauss.Interp, W=gauss.W)
+    r = sw2dComputeRHS_curved(h, hu, hv, hN, zx, zy, g, H, f, CD, ref_ctx, ref_cub, ref_gauss, curvedEls, J,
+                              gmapM, gmapP)
+    np.savez_compressed(
+        os.path.join(HERE, f"sw2d_rhs_curved_{name}.npz"), order=order, g=g, f=f, CD=CD, h=h, hu=hu, hv=hv, hN=hN,
+        H=H, zx=zx, zy=zy, x=x, y=y, x0=x0, y0=y0, J=J, V=ctx.V, Filter=ctx.filter, curvedEls=curvedEls.astype(np.int32),
+        NGauss=gauss.NGauss, NCubature=cub.NCubature, cubV=cub.V, cubDr=cub.Dr, cubDs=cub.Ds, cubW=cub.W,
+        cubrx=cub.rx, cubry=cub.ry, cubsx=cub.sx, cubsy=cub.sy, MMChol=cub.MMChol, gInterp=gauss.Interp, gW=gauss.W,
+        gnx=gauss.nx, gny=gauss.ny, gmapM=gmapM, gmapP=gmapP, gmapW=gmapW,
+        rhs1=r[0], rhs2=r[1], rhs3=r[2], rhs4=r[3])
+    print(f"sw2d_rhs_curved_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} Ncub={cub.NumCubaturePoints} "
+          f"curved={len(curvedEls)}/{len(moved)} moved |rhs|max={max(abs(a).max() for a in r):.6g}")
+
+
 def script_functions(path, names):
     """The named top-level function definitions of a reference SCRIPT (one that cannot be imported
     because its module body needs pyblitzdg and runs a whole simulation), compiled on their own with
@@ -242,7 +324,29 @@ def main():
     rhsC_case("coarse_box_N3", coarse, 3)
     rhsC_case("box6x5_shuffled_N6", shuffled, 6)
     advec1d_case()
+    curved_cases()
+
+
+def curved_cases():
+    import blitzdg_amd.pyblitzdg as dg
+    coarse = dg.MeshManager()
+    coarse.readMesh(os.path.join(HERE, "coarse_box.msh"))
+    shuffled = dg.MeshManager()
+    shuffled.buildBoxMesh(6, 5, shuffleSeed=12345)
+    box = dg.MeshManager()
+    box.buildBoxMesh(3, 2)
+    wall_bump = lambda x, y: bump_deformation(x, y, (0.55, -1.0), 0.9, (0.03, 0.07))      # noqa: E731
+    inner_bump = lambda x, y: bump_deformation(x, y, (-0.2, 0.1), 0.8, (0.05, -0.04))     # noqa: E731
+    curved_case("coarse_box_N3", coarse, 3, wall_bump)
+    curved_case("coarse_box_N4", coarse, 4, wall_bump)
+    curved_case("box6x5_shuffled_N6", shuffled, 6, inner_bump, flag="half")
+    curved_case("box6x5_periodic_N2", shuffled, 2, lambda x, y: bump_deformation(x, y, (0.0, 1.0), 0.7, (0.0, 0.06)),
+                periodic_x=True)
+    curved_case("box3x2_N8", box, 8, wall_bump)
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "curved":
+        curved_cases()
+    else:
+        main()
