@@ -65,6 +65,18 @@ class Sw2dVbDesc(Structure):
                 ("tide_period", c_double), ("tide_ramp", c_double), ("sponge", c_void_p)]
 
 
+class Sw2dCurvedDesc(Structure):
+    _fields_ = [("order", c_int), ("num_elements", c_int), ("num_cub", c_int), ("num_gauss", c_int),
+                ("V", c_void_p), ("Filter", c_void_p), ("J", c_void_p),
+                ("cubV", c_void_p), ("cubDr", c_void_p), ("cubDs", c_void_p),
+                ("cubW", c_void_p), ("cubrx", c_void_p), ("cubry", c_void_p), ("cubsx", c_void_p), ("cubsy", c_void_p),
+                ("gaussInterp", c_void_p), ("gaussW", c_void_p), ("gaussnx", c_void_p), ("gaussny", c_void_p),
+                ("gmapM", c_void_p), ("gmapP", c_void_p), ("gmapW", c_void_p), ("num_wall", c_int),
+                ("curvedEls", c_void_p), ("num_curved", c_int), ("MMChol", c_void_p),
+                ("zx", c_void_p), ("zy", c_void_p), ("coriolis", c_void_p), ("coriolis_const", c_double),
+                ("drag", c_void_p), ("drag_const", c_double), ("g", c_double), ("device", c_int), ("flags", c_int)]
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -180,6 +192,17 @@ _SIGNATURES = {
     "bdg_sw2d_is_renumbered": (c_int, [_P]),
     "bdg_sw2d_device_bytes": (c_size_t, [_P]),
     "bdg_sw2d_stream": (c_void_p, [_P]),
+    "bdg_sw2d_curved_create": (c_int, [POINTER(Sw2dCurvedDesc), POINTER(_P)]),
+    "bdg_sw2d_curved_destroy": (None, [_P]),
+    "bdg_sw2d_curved_rhs": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int]),
+    "bdg_sw2d_curved_set_state": (c_int, [_P, _P, _P, _P, _P]),
+    "bdg_sw2d_curved_get_state": (c_int, [_P, _P, _P, _P, _P]),
+    "bdg_sw2d_curved_step_rk2": (c_int, [_P, c_double, c_int, c_int]),
+    "bdg_sw2d_curved_lserk4_stages": (c_int, [_P, c_double, c_int]),
+    "bdg_sw2d_curved_time_rk2": (c_int, [_P, c_double, c_int, c_int, POINTER(c_float)]),
+    "bdg_sw2d_curved_synchronize": (c_int, [_P]),
+    "bdg_sw2d_curved_device_bytes": (c_size_t, [_P]),
+    "bdg_sw2d_curved_bytes_per_element": (c_double, [_P]),
 }
 
 #: every symbol include/blitzdg_hip.h declares (checked by tests/test_capi_symbols.py)

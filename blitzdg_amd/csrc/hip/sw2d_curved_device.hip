@@ -1,0 +1,481 @@
+// C ABI of the curved / over-integrated sw2d solver (include/blitzdg_hip.h, bdg_sw2d_curved_*): table
+// validation, device layout, operator image in MFMA tile order, launches. Kernels: sw2d_curved_kernel.hpp.
+// Reference: swhelpers/rhs.py:6-176 (the RHS), sw2d_curved.py:246-277 (the time loop).
+#include "../host/capi_internal.hpp"
+#include "blitzdg/LSERK4.hpp"
+#include "sw2d_curved_kernel.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace bdg_dev {
+const CurvedKernelTable* curved_kernel_table_order1();
+const CurvedKernelTable* curved_kernel_table_order2();
+const CurvedKernelTable* curved_kernel_table_order3();
+const CurvedKernelTable* curved_kernel_table_order4();
+const CurvedKernelTable* curved_kernel_table_order5();
+const CurvedKernelTable* curved_kernel_table_order6();
+const CurvedKernelTable* curved_kernel_table_order7();
+const CurvedKernelTable* curved_kernel_table_order8();
+
+const CurvedKernelTable* curved_kernel_table(int order) {
+    switch (order) {
+    case 1: return curved_kernel_table_order1();
+    case 2: return curved_kernel_table_order2();
+    case 3: return curved_kernel_table_order3();
+    case 4: return curved_kernel_table_order4();
+    case 5: return curved_kernel_table_order5();
+    case 6: return curved_kernel_table_order6();
+    case 7: return curved_kernel_table_order7();
+    case 8: return curved_kernel_table_order8();
+    default: return nullptr;
+    }
+}
+} // namespace bdg_dev
+
+using bdg_detail::arg_error;
+using bdg_detail::guard;
+using bdg_detail::hip_error;
+
+namespace {
+
+void hipOk(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw hip_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <typename T>
+struct Buf {
+    T* p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count, size_t& total, hipStream_t stream) {
+        release();
+        if (count == 0) return;
+        hipOk(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)), "hipMalloc");
+        n = count;
+        total += count * sizeof(T);
+        hipOk(hipMemsetAsync(p, 0, count * sizeof(T), stream), "hipMemset");
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~Buf() { release(); }
+};
+
+} // namespace
+
+struct bdg_sw2d_curved {
+    const bdg_dev::CurvedKernelTable* kt = nullptr;
+    int N = 0, Np = 0, K = 0, device = 0, ncub = 0, ncb = 0, ng = 0, fb = 0, numCurved = 0;
+    long long ld = 0, sideLd = 0;
+    bool hasFilter = false, identityM = true;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t bytes = 0;
+    Buf<double> qA, qB, res, rhs, gq, cubG, gaussG, rJ, zx, zy, fcor, cd, mmSide, cholSide, ops, filt;
+    Buf<int> gmapP, gmapM, curvedSlot, curvedEls;
+    double g = 9.81, fconst = 0.0, cdconst = 0.0;
+    long long stageCount = 0;
+    double bytesPerElement = 0.0;
+
+    ~bdg_sw2d_curved() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void use() const { hipOk(hipSetDevice(device), "hipSetDevice"); }
+    size_t plane() const { return static_cast<size_t>(Np) * static_cast<size_t>(ld); }
+
+    // host (rows, K) row-major -> device rows [row0, row0 + rows) of a (., ld) plane
+    template <typename T>
+    void uploadRows(const T* host, T* dev, int rows, int row0 = 0) {
+        hipOk(hipMemcpy2DAsync(dev + static_cast<size_t>(row0) * ld, static_cast<size_t>(ld) * sizeof(T), host,
+                               static_cast<size_t>(K) * sizeof(T), static_cast<size_t>(K) * sizeof(T), rows,
+                               hipMemcpyHostToDevice, stream), "H2D copy");
+        hipOk(hipStreamSynchronize(stream), "upload sync");
+    }
+    void downloadRows(const double* dev, double* host, int rows) {
+        hipOk(hipMemcpy2DAsync(host, static_cast<size_t>(K) * sizeof(double), dev, static_cast<size_t>(ld) * sizeof(double),
+                               static_cast<size_t>(K) * sizeof(double), rows, hipMemcpyDeviceToHost, stream), "D2H copy");
+        hipOk(hipStreamSynchronize(stream), "download sync");
+    }
+
+    bdg_dev::CurvedParams params() const {
+        bdg_dev::CurvedParams p{};
+        p.gq = gq.p; p.cubG = cubG.p; p.gaussG = gaussG.p; p.gmapP = gmapP.p; p.gmapM = identityM ? nullptr : gmapM.p;
+        p.rJ = rJ.p; p.zx = zx.p; p.zy = zy.p; p.fcor = fcor.p; p.cd = cd.p; p.fconst = fconst; p.cdconst = cdconst;
+        p.curvedSlot = numCurved ? curvedSlot.p : nullptr;
+        p.mmSide = mmSide.p; p.cholSide = cholSide.p; p.curvedEls = curvedEls.p; p.numCurved = numCurved; p.sideLd = sideLd;
+        p.ops = ops.p; p.filt = filt.p; p.ld = ld; p.K = K; p.ncb = ncb; p.ncub = ncub; p.ng = ng; p.fb = fb; p.g = g;
+        return p;
+    }
+
+    // One RHS evaluation fused with its update: Gauss traces of qin, stage kernel, curved-element kernel.
+    void evaluate(int mode, bool filter, const double* qin, const double* qbase, double* qout, double ca, double cb,
+                  double cc) {
+        if (filter && !hasFilter) throw arg_error("bdg_sw2d_curved: filter requested but the solver was created without a Filter matrix");
+        bdg_dev::CurvedParams p = params();
+        p.qin = qin; p.qbase = qbase; p.qout = qout; p.res = res.p; p.rhs = rhs.p; p.ca = ca; p.cb = cb; p.cc = cc;
+        hipOk(kt->gauss(p, stream), "sw2d_curved_gauss_kernel");
+        hipOk(kt->stage(mode, filter, p, stream), "sw2d_curved_stage_kernel");
+        hipOk(kt->fixup(mode, filter, p, stream), "sw2d_curved_fixup_kernel");
+    }
+
+    void stepRk2(double dt, int steps, bool filter) {
+        for (int i = 0; i < steps; ++i) {
+            evaluate(bdg_dev::CMODE_COMBINE, filter, qA.p, qA.p, qB.p, 1.0, 0.0, 0.5 * dt); // predictor: q1 = q + dt/2 RHS(q)
+            evaluate(bdg_dev::CMODE_COMBINE, filter, qB.p, qA.p, qA.p, 1.0, 0.0, dt);       // corrector: q += dt RHS(q1)
+        }
+    }
+};
+
+namespace {
+
+void requireCurved(const bdg_sw2d_curved* s, const char* fn) {
+    if (!s) throw arg_error(std::string(fn) + ": solver handle is NULL");
+}
+
+std::vector<double> matmul(const double* A, const double* B, int n, int m, int c) { // (n,m) (m,c)
+    std::vector<double> C(static_cast<size_t>(n) * c, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < m; ++k) {
+            const double a = A[static_cast<size_t>(i) * m + k];
+            for (int j = 0; j < c; ++j) C[static_cast<size_t>(i) * c + j] += a * B[static_cast<size_t>(k) * c + j];
+        }
+    return C;
+}
+
+bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
+    const bdg_dev::CurvedKernelTable* kt = bdg_dev::curved_kernel_table(d.order);
+    if (!kt) throw arg_error("bdg_sw2d_curved_create: order must be 1..8");
+    if (d.num_elements < 1 || d.num_cub < 1 || d.num_gauss < 1) throw arg_error("bdg_sw2d_curved_create: bad sizes");
+    if (!d.V || !d.J || !d.cubV || !d.cubDr || !d.cubDs || !d.cubW || !d.cubrx || !d.cubry || !d.cubsx || !d.cubsy ||
+        !d.gaussInterp || !d.gaussW || !d.gaussnx || !d.gaussny || !d.gmapM || !d.gmapP)
+        throw arg_error("bdg_sw2d_curved_create: a required table pointer is NULL");
+    if (d.num_wall < 0 || (d.num_wall > 0 && !d.gmapW)) throw arg_error("bdg_sw2d_curved_create: bad wall-node list");
+    if (d.num_curved < 0 || (d.num_curved > 0 && (!d.curvedEls || !d.MMChol)))
+        throw arg_error("bdg_sw2d_curved_create: curvedEls given without MMChol (or a negative count)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        throw hip_error("bdg_sw2d_curved_create: no HIP device available (the sw2d path has no CPU fallback)");
+    if (d.device < 0 || d.device >= ndev) throw arg_error("bdg_sw2d_curved_create: device ordinal out of range");
+
+    auto s = std::unique_ptr<bdg_sw2d_curved>(new bdg_sw2d_curved());
+    s->kt = kt;
+    s->N = d.order; s->Np = kt->Np; s->K = d.num_elements; s->device = d.device; s->g = d.g;
+    s->ncub = d.num_cub; s->ncb = (d.num_cub + 15) / 16; s->ng = d.num_gauss; s->fb = (d.num_gauss + 15) / 16;
+    s->ld = (static_cast<long long>(s->K) + 63) / 64 * 64;
+    const int Np = s->Np, K = s->K, Ncub = s->ncub, NG = s->ng, NG3 = 3 * NG, ncb = s->ncb, fb = s->fb;
+    const int CR = 16 * ncb, GR = 48 * fb, KV = kt->KV, MT = kt->MT;
+    const long long ld = s->ld;
+    // lane addresses are a row pointer plus an unsigned 32-bit BYTE offset within one plane
+    if (static_cast<long long>(std::max({Np, CR, GR})) * ld * 8 > 4294967295LL)
+        throw arg_error("bdg_sw2d_curved_create: a table plane exceeds 4 GiB (32-bit byte offsets): partition the mesh");
+
+    // ---- index tables, validated on the host before anything touches the GPU
+    const long long nG = static_cast<long long>(NG3) * K;
+    std::vector<int> offP(static_cast<size_t>(GR) * K, 0), offM;
+    bool identityM = true;
+    for (long long i = 0; i < nG; ++i) {
+        if (d.gmapP[i] < 0 || d.gmapP[i] >= nG || d.gmapM[i] < 0 || d.gmapM[i] >= nG)
+            throw arg_error("bdg_sw2d_curved_create: gmapM / gmapP entry out of range");
+        identityM = identityM && d.gmapM[i] == i;
+    }
+    auto devOffset = [&](int v) { // flat id g + 3NG k -> padded row * ld + k
+        const int k2 = v / NG3, g2 = v % NG3, f2 = g2 / NG, l2 = g2 % NG;
+        return static_cast<int>((16ll * fb * f2 + l2) * ld + k2);
+    };
+    if (!identityM) offM.assign(static_cast<size_t>(GR) * K, 0);
+#pragma omp parallel for schedule(static)
+    for (int k = 0; k < K; ++k)
+        for (int gI = 0; gI < NG3; ++gI) {
+            const int f = gI / NG, l = gI % NG;
+            const size_t at = static_cast<size_t>(16 * fb * f + l) * K + k;
+            offP[at] = devOffset(d.gmapP[static_cast<size_t>(k) * NG3 + gI]);
+            if (!identityM) offM[at] = devOffset(d.gmapM[static_cast<size_t>(k) * NG3 + gI]);
+        }
+    for (int i = 0; i < d.num_wall; ++i) {
+        const int w = d.gmapW[i];
+        if (w < 0 || w >= nG) throw arg_error("bdg_sw2d_curved_create: wall Gauss-node index out of range");
+        const int k = w / NG3, gI = w % NG3, f = gI / NG, l = gI % NG;
+        int& e = offP[static_cast<size_t>(16 * fb * f + l) * K + k];
+        if (e >= 0) e = -(e + 1);
+    }
+    std::vector<int> curved;
+    std::vector<int> slotOf(static_cast<size_t>(K), -1);
+    for (int i = 0; i < d.num_curved; ++i) {
+        const int k = d.curvedEls[i];
+        if (k < 0 || k >= K) throw arg_error("bdg_sw2d_curved_create: curvedEls entry out of range");
+        if (slotOf[k] < 0) { // the reference takes set(curvedEls)
+            slotOf[k] = static_cast<int>(curved.size());
+            curved.push_back(k);
+        }
+    }
+    s->numCurved = static_cast<int>(curved.size());
+    s->sideLd = (static_cast<long long>(s->numCurved) + 63) / 64 * 64;
+    s->identityM = identityM;
+
+    s->use();
+    hipOk(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
+    hipOk(hipEventCreate(&s->ev0), "hipEventCreate");
+    hipOk(hipEventCreate(&s->ev1), "hipEventCreate");
+    hipStream_t st = s->stream;
+
+    // ---- state and work planes
+    const size_t plane4 = 4 * s->plane();
+    s->qA.alloc(plane4, s->bytes, st);
+    s->qB.alloc(plane4, s->bytes, st);
+    s->res.alloc(plane4, s->bytes, st);
+    s->rhs.alloc(plane4, s->bytes, st);
+    s->gq.alloc(static_cast<size_t>(4) * GR * ld, s->bytes, st);
+
+    // ---- cubature geometry: W rx, W ry, W sx, W sy (the reference forms W (rx F + ry G); the products are
+    //      folded here once, a rounding-level difference), rows padded to 16 ncb with zeros
+    s->cubG.alloc(static_cast<size_t>(4) * CR * ld, s->bytes, st);
+    {
+        std::vector<double> tmp(static_cast<size_t>(Ncub) * K);
+        const double* geo[4] = {d.cubrx, d.cubry, d.cubsx, d.cubsy};
+        for (int t = 0; t < 4; ++t) {
+#pragma omp parallel for schedule(static)
+            for (long long i = 0; i < static_cast<long long>(Ncub) * K; ++i) tmp[i] = d.cubW[i] * geo[t][i];
+            s->uploadRows(tmp.data(), s->cubG.p + static_cast<size_t>(t) * CR * ld, Ncub);
+        }
+    }
+    // ---- Gauss geometry nx, ny, W and the maps, each face padded to 16 fb rows
+    s->gaussG.alloc(static_cast<size_t>(3) * GR * ld, s->bytes, st);
+    {
+        const double* geo[3] = {d.gaussnx, d.gaussny, d.gaussW};
+        for (int t = 0; t < 3; ++t)
+            for (int f = 0; f < 3; ++f)
+                s->uploadRows(geo[t] + static_cast<size_t>(f) * NG * K, s->gaussG.p + static_cast<size_t>(t) * GR * ld, NG, 16 * fb * f);
+    }
+    s->gmapP.alloc(static_cast<size_t>(GR) * ld, s->bytes, st);
+    s->uploadRows(offP.data(), s->gmapP.p, GR);
+    if (!identityM) {
+        s->gmapM.alloc(static_cast<size_t>(GR) * ld, s->bytes, st);
+        s->uploadRows(offM.data(), s->gmapM.p, GR);
+    }
+    // ---- nodal tables
+    s->rJ.alloc(s->plane(), s->bytes, st);
+    {
+        std::vector<double> tmp(static_cast<size_t>(Np) * K);
+        for (size_t i = 0; i < tmp.size(); ++i) {
+            if (!(d.J[i] > 0.0)) throw arg_error("bdg_sw2d_curved_create: nodal Jacobian J must be positive");
+            tmp[i] = 1.0 / d.J[i];
+        }
+        s->uploadRows(tmp.data(), s->rJ.p, Np);
+    }
+    auto nodal = [&](const double* host, Buf<double>& buf) {
+        if (!host) return;
+        buf.alloc(s->plane(), s->bytes, st);
+        s->uploadRows(host, buf.p, Np);
+    };
+    nodal(d.zx, s->zx);
+    nodal(d.zy, s->zy);
+    nodal(d.coriolis, s->fcor);
+    nodal(d.drag, s->cd);
+    s->fconst = d.coriolis_const;
+    s->cdconst = d.drag_const;
+
+    // ---- elements of curvedEls: slot table, element list, Cholesky factors with the slot index contiguous
+    if (s->numCurved) {
+        s->curvedSlot.alloc(ld, s->bytes, st);
+        std::vector<int> slots(static_cast<size_t>(ld), -1);
+        std::copy(slotOf.begin(), slotOf.end(), slots.begin());
+        hipOk(hipMemcpyAsync(s->curvedSlot.p, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice, st), "slot upload");
+        s->curvedEls.alloc(curved.size(), s->bytes, st);
+        hipOk(hipMemcpyAsync(s->curvedEls.p, curved.data(), curved.size() * sizeof(int), hipMemcpyHostToDevice, st), "curvedEls upload");
+        const size_t sld = static_cast<size_t>(s->sideLd);
+        std::vector<double> chol(static_cast<size_t>(Np) * Np * sld, 0.0);
+        for (size_t c = 0; c < curved.size(); ++c)
+            for (int i = 0; i < Np; ++i) {
+                for (int jj = 0; jj < Np; ++jj)
+                    chol[(static_cast<size_t>(i) * Np + jj) * sld + c] = d.MMChol[(static_cast<size_t>(i) * Np + jj) * K + curved[c]];
+                if (!(d.MMChol[(static_cast<size_t>(i) * Np + i) * K + curved[c]] > 0.0))
+                    throw arg_error("bdg_sw2d_curved_create: MMChol has a non-positive diagonal entry on an element of curvedEls");
+            }
+        s->cholSide.alloc(chol.size(), s->bytes, st);
+        hipOk(hipMemcpyAsync(s->cholSide.p, chol.data(), chol.size() * sizeof(double), hipMemcpyHostToDevice, st), "chol upload");
+        s->mmSide.alloc(static_cast<size_t>(4) * Np * sld, s->bytes, st);
+        hipOk(hipStreamSynchronize(st), "side upload sync");
+    }
+
+    // ---- operator image in MFMA A-tile order (layout: CurvedOps in sw2d_curved_kernel.hpp)
+    s->hasFilter = d.Filter != nullptr;
+    {
+        int off[8];
+        kt->opsOffsets(ncb, fb, off);
+        std::vector<double> img(static_cast<size_t>(kt->opsTiles(ncb, fb)) * 64, 0.0);
+        auto at = [&](int tile, int l) -> double& { return img[static_cast<size_t>(tile) * 64 + l]; };
+        std::vector<double> Vt(static_cast<size_t>(Np) * Np);
+        for (int i = 0; i < Np; ++i)
+            for (int jj = 0; jj < Np; ++jj) Vt[static_cast<size_t>(i) * Np + jj] = d.V[static_cast<size_t>(jj) * Np + i];
+        const std::vector<double> M = matmul(d.V, Vt.data(), Np, Np, Np);
+        std::vector<double> MF, ident(static_cast<size_t>(Np) * Np, 0.0);
+        if (d.Filter) MF = matmul(d.Filter, M.data(), Np, Np, Np);
+        for (int l = 0; l < 64; ++l) {
+            const int i = l & 15, sc = l >> 4;
+            for (int rb = 0; rb < ncb; ++rb)
+                for (int t = 0; t < KV; ++t) {
+                    const int row = 16 * rb + i, m = 4 * t + sc;
+                    if (row < Ncub && m < Np) at(off[0] + rb * KV + t, l) = d.cubV[static_cast<size_t>(row) * Np + m];
+                }
+            for (int r = 0; r < MT; ++r)
+                for (int rb = 0; rb < ncb; ++rb)
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int node = 16 * r + i, cp = 16 * rb + 4 * reg + sc;
+                        if (node < Np && cp < Ncub) {
+                            at(off[1] + (r * ncb + rb) * 4 + reg, l) = d.cubDr[static_cast<size_t>(cp) * Np + node];
+                            at(off[2] + (r * ncb + rb) * 4 + reg, l) = d.cubDs[static_cast<size_t>(cp) * Np + node];
+                        }
+                    }
+            for (int r = 0; r < MT; ++r)
+                for (int gb = 0; gb < 3 * fb; ++gb)
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int node = 16 * r + i, f = gb / fb, local = 16 * (gb % fb) + 4 * reg + sc;
+                        if (node < Np && local < NG)
+                            at(off[3] + (r * 3 * fb + gb) * 4 + reg, l) = -d.gaussInterp[static_cast<size_t>(f * NG + local) * Np + node];
+                    }
+            for (int r = 0; r < MT; ++r)
+                for (int t = 0; t < KV; ++t) {
+                    const int node = 16 * r + i, m = 4 * t + sc;
+                    if (node < Np && m < Np) {
+                        at(off[4] + r * KV + t, l) = M[static_cast<size_t>(node) * Np + m];
+                        if (d.Filter) {
+                            at(off[5] + r * KV + t, l) = MF[static_cast<size_t>(node) * Np + m];
+                            at(off[6] + r * KV + t, l) = d.Filter[static_cast<size_t>(node) * Np + m];
+                        }
+                    }
+                }
+            for (int gb = 0; gb < 3 * fb; ++gb)
+                for (int t = 0; t < KV; ++t) {
+                    const int f = gb / fb, local = 16 * (gb % fb) + i, m = 4 * t + sc;
+                    if (local < NG && m < Np) at(off[7] + gb * KV + t, l) = d.gaussInterp[static_cast<size_t>(f * NG + local) * Np + m];
+                }
+        }
+        s->ops.alloc(img.size(), s->bytes, st);
+        hipOk(hipMemcpyAsync(s->ops.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, st), "ops upload");
+        if (d.Filter) {
+            s->filt.alloc(static_cast<size_t>(Np) * Np, s->bytes, st);
+            hipOk(hipMemcpyAsync(s->filt.p, d.Filter, static_cast<size_t>(Np) * Np * sizeof(double), hipMemcpyHostToDevice, st), "filter upload");
+        }
+        hipOk(hipStreamSynchronize(st), "ops sync");
+    }
+    // compulsory bytes of one RHS evaluation per element: state in, RHS out, geometry, maps, traces out and in (twice: both sides)
+    s->bytesPerElement = 8.0 * (4 * Np /*q*/ + 4 * Np /*out*/ + 4 * Ncub + 3 * NG3 + Np /*rJ*/ + (d.zx ? Np : 0) + (d.zy ? Np : 0) +
+                                (d.coriolis ? Np : 0) + (d.drag ? Np : 0) + 4 * Np /*q, trace kernel*/ + 3 * 4 * NG3 /*gq write, read M, read P*/) +
+                         4.0 * (NG3 * (identityM ? 1 : 2) + 1);
+    return s.release();
+}
+
+} // namespace
+
+extern "C" {
+
+int bdg_sw2d_curved_create(const bdg_sw2d_curved_desc* desc, bdg_sw2d_curved** out) {
+    return guard([&] {
+        if (!desc || !out) throw arg_error("bdg_sw2d_curved_create: NULL argument");
+        *out = createCurved(*desc);
+    });
+}
+
+void bdg_sw2d_curved_destroy(bdg_sw2d_curved* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    delete s;
+}
+
+int bdg_sw2d_curved_rhs(bdg_sw2d_curved* s, const double* h, const double* hu, const double* hv, const double* hN,
+                        double* r1, double* r2, double* r3, double* r4, int filter) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_rhs");
+        if (!h || !hu || !hv || !hN || !r1 || !r2 || !r3 || !r4) throw arg_error("bdg_sw2d_curved_rhs: NULL field pointer");
+        s->use();
+        const size_t pl = s->plane();
+        const double* in[4] = {h, hu, hv, hN};
+        double* outp[4] = {r1, r2, r3, r4};
+        for (int c = 0; c < 4; ++c) s->uploadRows(in[c], s->qB.p + c * pl, s->Np); // the scratch state: qA stays untouched
+        s->evaluate(bdg_dev::CMODE_RHS, filter != 0, s->qB.p, nullptr, nullptr, 0.0, 0.0, 0.0);
+        for (int c = 0; c < 4; ++c) s->downloadRows(s->rhs.p + c * pl, outp[c], s->Np);
+    });
+}
+
+int bdg_sw2d_curved_set_state(bdg_sw2d_curved* s, const double* h, const double* hu, const double* hv, const double* hN) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_set_state");
+        if (!h || !hu || !hv || !hN) throw arg_error("bdg_sw2d_curved_set_state: NULL field pointer");
+        s->use();
+        const double* in[4] = {h, hu, hv, hN};
+        for (int c = 0; c < 4; ++c) s->uploadRows(in[c], s->qA.p + c * s->plane(), s->Np);
+        hipOk(hipMemsetAsync(s->res.p, 0, s->res.n * sizeof(double), s->stream), "hipMemset");
+        s->stageCount = 0;
+    });
+}
+
+int bdg_sw2d_curved_get_state(bdg_sw2d_curved* s, double* h, double* hu, double* hv, double* hN) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_get_state");
+        if (!h || !hu || !hv || !hN) throw arg_error("bdg_sw2d_curved_get_state: NULL field pointer");
+        s->use();
+        double* outp[4] = {h, hu, hv, hN};
+        for (int c = 0; c < 4; ++c) s->downloadRows(s->qA.p + c * s->plane(), outp[c], s->Np);
+    });
+}
+
+int bdg_sw2d_curved_step_rk2(bdg_sw2d_curved* s, double dt, int num_steps, int filter) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_step_rk2");
+        if (num_steps < 0) throw arg_error("bdg_sw2d_curved_step_rk2: num_steps < 0");
+        s->use();
+        s->stepRk2(dt, num_steps, filter != 0);
+    });
+}
+
+int bdg_sw2d_curved_lserk4_stages(bdg_sw2d_curved* s, double dt, int num_stages) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_lserk4_stages");
+        if (num_stages < 0) throw arg_error("bdg_sw2d_curved_lserk4_stages: num_stages < 0");
+        s->use();
+        for (int i = 0; i < num_stages; ++i) {
+            const int st = static_cast<int>(s->stageCount % blitzdg::LSERK4::numStages);
+            // res = a res + dt RHS(q); q += b res   (reference src/advec1d/main.cpp:92-102), in place: only own
+            // elements are read from q by the stage kernel, the neighbours' traces come from gq
+            s->evaluate(bdg_dev::CMODE_LSERK, false, s->qA.p, nullptr, s->qA.p, blitzdg::LSERK4::rk4a[st],
+                        blitzdg::LSERK4::rk4b[st], dt);
+            ++s->stageCount;
+        }
+    });
+}
+
+int bdg_sw2d_curved_time_rk2(bdg_sw2d_curved* s, double dt, int num_steps, int filter, float* ms_per_rhs) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_time_rk2");
+        if (num_steps < 1 || !ms_per_rhs) throw arg_error("bdg_sw2d_curved_time_rk2: bad argument");
+        s->use();
+        hipOk(hipEventRecord(s->ev0, s->stream), "hipEventRecord");
+        s->stepRk2(dt, num_steps, filter != 0);
+        hipOk(hipEventRecord(s->ev1, s->stream), "hipEventRecord");
+        hipOk(hipEventSynchronize(s->ev1), "hipEventSynchronize");
+        float ms = 0.f;
+        hipOk(hipEventElapsedTime(&ms, s->ev0, s->ev1), "hipEventElapsedTime");
+        *ms_per_rhs = ms / (2.0f * static_cast<float>(num_steps));
+    });
+}
+
+int bdg_sw2d_curved_synchronize(bdg_sw2d_curved* s) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_synchronize");
+        s->use();
+        hipOk(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+    });
+}
+
+size_t bdg_sw2d_curved_device_bytes(const bdg_sw2d_curved* s) { return s ? s->bytes : 0; }
+double bdg_sw2d_curved_bytes_per_element(const bdg_sw2d_curved* s) { return s ? s->bytesPerElement : 0.0; }
+
+} // extern "C"

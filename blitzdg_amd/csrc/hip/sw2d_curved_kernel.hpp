@@ -1,0 +1,479 @@
+// sw2d_curved_kernel.hpp -- curved / over-integrated shallow-water RHS on the matrix cores.
+//
+// Reference: swhelpers.rhs.sw2dComputeRHS_curved (swhelpers/rhs.py:6-176) as driven by sw2d_curved.py:246-277.
+// Per element, with q = (h, hu, hv, hN) at the Np nodes:
+//     cub_q   = Vc q                                     (Ncub x Np) interpolation to the cubature points
+//     MM_c    = DrT (W (rx F_c + ry G_c)) + DsT (W (sx F_c + sy G_c))           fluxes at the cubature points
+//     MM_c   -= InterpT (gW * 1/2 ((F_cM + F_cP) nx + (G_cM + G_cP) ny + lam (q_cM - q_cP)))   at the Gauss face points
+//     RHS_c   = (V V^T) (MM_c / J)    straight-sided elements;    U^-1 U^-T MM_c    elements listed in curvedEls
+//     RHS_2,3 += Coriolis, drag, bed slope at the nodes
+// Every one of these is a dense contraction over 4..200 points, batched over the elements: for a tile of 16
+// elements it is a chain of v_mfma_f64_16x16x4_f64 products whose B operands and C results never leave
+// registers. Lane l = (q = l >> 4, j = l & 15) works on element j of the tile; as a B operand it supplies
+// contraction index q of a 4-deep step, and a C result hands it rows q, q+4, q+8, q+12 of a 16-row block -- which
+// are again "index q of step reg" of the next product, so C of one product is fed straight back as B of the next
+// (cubature values -> weighted fluxes -> DrT/DsT; Gauss fluxes -> InterpT; MM / J -> mass inverse), the A tiles
+// being stored with their columns in that order. The pointwise physics runs in operand layout with no cross-lane
+// traffic; only the per-face maximum of the wave speed crosses lanes (two xor shuffles per face).
+//
+// Launches per RHS evaluation:
+//   sw2d_curved_gauss_kernel   q -> Gauss traces gq (Interp q) of every element, (4, GR, ld) planes
+//   sw2d_curved_stage_kernel   everything above + RK update; neighbour traces gathered from gq through gmapP
+//                              (any map: periodic rewiring included); elements of curvedEls leave their raw MM_c
+//                              in a side buffer instead
+//   sw2d_curved_fixup_kernel   the elements of curvedEls: two triangular solves with their own Cholesky factor,
+//                              sources, filter, update (one lane per element; they are the few boundary elements)
+// Tables are (rows, ld) planes, element index contiguous; a wave touches 128-byte row segments.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace bdg_dev {
+
+typedef double cmfma_t __attribute__((ext_vector_type(4)));
+
+enum { CMODE_RHS = 0, CMODE_LSERK = 1, CMODE_COMBINE = 2 };
+
+struct CurvedParams {
+    const double* qin;    // 4 planes of Np*ld: h, hu, hv, hN
+    const double* qbase;  // CMODE_COMBINE
+    double* qout;         // CMODE_LSERK / CMODE_COMBINE (may alias qin or qbase: only own elements are read from them)
+    double* res;          // CMODE_LSERK
+    double* rhs;          // CMODE_RHS
+    double* gq;           // Gauss traces, 4 planes of GR*ld (GR = 48*fb rows: every face padded to 16*fb rows)
+    const double* cubG;   // 4 planes of CR*ld (CR = 16*ncb, zero padded): W rx, W ry, W sx, W sy
+    const double* gaussG; // 3 planes of GR*ld (zero padded): nx, ny, W
+    const int* gmapP;     // GR*ld: offset row*ld + k into a gq plane; wall Gauss nodes stored as -(offset+1)
+    const int* gmapM;     // the same for the interior side, or nullptr when gmapM is the identity
+    const double* rJ;     // Np*ld: 1 / J at the nodes
+    const double* zx;     // Np*ld or nullptr
+    const double* zy;
+    const double* fcor;   // Np*ld or nullptr (then fconst)
+    const double* cd;     // Np*ld or nullptr (then cdconst)
+    double fconst, cdconst;
+    const int* curvedSlot; // ld: index into the side buffer for elements of curvedEls, -1 otherwise (nullptr: none)
+    double* mmSide;        // 4*Np rows of sideLd: raw MM_c of the curved elements
+    const double* cholSide; // Np*Np rows of sideLd: their upper Cholesky factors
+    const int* curvedEls;  // element slot of each side-buffer column
+    int numCurved;
+    long long sideLd;
+    const double* ops;    // operator image (CurvedOps layout), 64 doubles per tile
+    const double* filt;   // (Np, Np) row-major filter for the fix-up kernel, or nullptr
+    long long ld;
+    int K;
+    int ncb;              // 16-row blocks of cubature points
+    int ncub;             // cubature points
+    int ng;               // Gauss points per face
+    int fb;               // 16-row blocks per face
+    double g, ca, cb, cc;
+};
+
+// Operator image: zero-padded 16 x 4 A tiles, 64 doubles each, entry l of a tile = A[row l & 15][step column l >> 4].
+//   Vc   [rb][t]       row 16 rb + i = cubature point,      column 4 t + s = node
+//   DrT  [r][rb][reg]  row 16 r + i = node,                 column s <-> cubature point 16 rb + 4 reg + s   (Dr_cub^T)
+//   DsT  likewise
+//   IT   [r][gb][reg]  row 16 r + i = node,                 column s <-> Gauss row 16 b + 4 reg + s of face gb / fb   (-Interp^T)
+//   M    [r][t]        row 16 r + i = node,                 column 4 t + s = node       V V^T
+//   MF   [r][t]        Filter V V^T
+//   F    [r][t]        Filter
+//   GI   [gb][t]       row 16 b + i = Gauss row of a face,  column 4 t + s = node       Interp (Gauss kernel)
+template <int N>
+struct CurvedOps {
+    static constexpr int Np = (N + 1) * (N + 2) / 2;
+    static constexpr int KV = (Np + 3) / 4;
+    static constexpr int MT = (Np + 15) / 16;
+    __host__ __device__ static constexpr int offVc(int, int) { return 0; }
+    __host__ __device__ static constexpr int offDrT(int ncb, int) { return ncb * KV; }
+    __host__ __device__ static constexpr int offDsT(int ncb, int fb) { return offDrT(ncb, fb) + MT * ncb * 4; }
+    __host__ __device__ static constexpr int offIT(int ncb, int fb) { return offDsT(ncb, fb) + MT * ncb * 4; }
+    __host__ __device__ static constexpr int offM(int ncb, int fb) { return offIT(ncb, fb) + MT * 3 * fb * 4; }
+    __host__ __device__ static constexpr int offMF(int ncb, int fb) { return offM(ncb, fb) + MT * KV; }
+    __host__ __device__ static constexpr int offF(int ncb, int fb) { return offMF(ncb, fb) + MT * KV; }
+    __host__ __device__ static constexpr int offGI(int ncb, int fb) { return offF(ncb, fb) + MT * KV; }
+    __host__ __device__ static constexpr int tiles(int ncb, int fb) { return offGI(ncb, fb) + 3 * fb * KV; }
+    // the stage kernel reads [0, offGI)
+};
+
+template <typename T>
+__device__ __forceinline__ T cld_row(const T* row, unsigned byteOff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(row) + byteOff);
+}
+template <typename T>
+__device__ __forceinline__ void cst_row(T* row, unsigned byteOff, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(row) + byteOff) = v;
+}
+
+// Tile range of this wave: XCD-aware (workgroups b and b + 8 share an XCD's L2), contiguous tiles per wave.
+__device__ __forceinline__ void curved_wave_tiles(unsigned ntiles, unsigned& first, unsigned& last) {
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const unsigned blk = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const unsigned wave = blk * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = nwg * (blockDim.x >> 6);
+    const unsigned per = (ntiles + nwaves - 1u) / nwaves;
+    first = wave * per;
+    last = min(ntiles, first + per);
+}
+
+// ---- Gauss traces of every element: gq_c = Interp q_c, faces padded to 16*fb rows (padding rows are never written)
+template <int N>
+__global__ __launch_bounds__(256) void sw2d_curved_gauss_kernel(const CurvedParams p) {
+    using O = CurvedOps<N>;
+    constexpr int Np = O::Np, KV = O::KV;
+    extern __shared__ double sOps[];
+    const int fb = p.fb, ngb = 3 * fb, offGI = O::offGI(p.ncb, fb);
+    for (int t = threadIdx.x; t < ngb * KV * 64; t += blockDim.x) sOps[t] = p.ops[static_cast<size_t>(offGI) * 64 + t];
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, gplane = 48ll * fb * ld;
+    const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u;
+    unsigned tile, tileEnd;
+    curved_wave_tiles(ntiles, tile, tileEnd);
+    for (; tile < tileEnd; ++tile) {
+        const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
+        const bool live = kTrue <= kLast;
+        const unsigned k8 = (live ? kTrue : kLast) * 8u;
+        double qB[4][KV];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const int m = 4 * t + static_cast<int>(q);
+                qB[c][t] = m < Np ? cld_row(p.qin + c * plane + m * ld, k8) : 0.0;
+            }
+        for (int gb = 0; gb < ngb; ++gb) {
+            cmfma_t gv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gv[c] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const double a = sOps[(gb * KV + t) * 64 + lane];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], gv[c], 0, 0, 0);
+            }
+            const int b = gb % fb;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int local = 16 * b + static_cast<int>(q) + 4 * reg, gr = 16 * gb + static_cast<int>(q) + 4 * reg;
+                if (live && local < p.ng) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cst_row(p.gq + c * gplane + gr * ld, k8, gv[c][reg]);
+                }
+            }
+        }
+    }
+}
+
+// Shallow-water fluxes of one point (reference swhelpers/flux.py:1-22), same operations in the same order.
+struct CurvedFlux {
+    double F[4], G[4];
+};
+__device__ __forceinline__ CurvedFlux curved_fluxes(double h, double hu, double hv, double hN, double g) {
+    const double u = hu / h, v = hv / h;
+    const double pr = 0.5 * g * h * h;
+    CurvedFlux o;
+    o.F[0] = hu;          o.G[0] = hv;
+    o.F[1] = hu * u + pr; o.G[1] = hu * v;
+    o.F[2] = hv * u;      o.G[2] = hv * v + pr;
+    o.F[3] = hN * u;      o.G[3] = hN * v;
+    return o;
+}
+
+// Momentum sources at a node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx,  S3 = -(f hu - CD |u| v) - g h zy.
+__device__ __forceinline__ void curved_sources(const CurvedParams& p, double h, double hu, double hv, long long rowOff,
+                                               unsigned k8, double& S2, double& S3) {
+    const double u = hu / h, v = hv / h;
+    const double f = p.fcor ? cld_row(p.fcor + rowOff, k8) : p.fconst;
+    const double cd = p.cd ? cld_row(p.cd + rowOff, k8) : p.cdconst;
+    const double cdn = cd * sqrt(u * u + v * v);
+    const double zx = p.zx ? cld_row(p.zx + rowOff, k8) : 0.0, zy = p.zy ? cld_row(p.zy + rowOff, k8) : 0.0;
+    S2 = (f * hv - cdn * u) - p.g * h * zx;
+    S3 = -(f * hu - cdn * v) - p.g * h * zy;
+}
+
+// MODE: CMODE_*; FILTER: the result is Filter * RHS (the drivers filter the whole RHS, sources included);
+// OPSLDS: operator tiles staged in LDS (else read from global memory / L2: images beyond the LDS budget).
+template <int N, int MODE, bool FILTER, bool OPSLDS>
+__global__ __launch_bounds__(256) void sw2d_curved_stage_kernel(const CurvedParams p) {
+    using O = CurvedOps<N>;
+    constexpr int Np = O::Np, KV = O::KV, MT = O::MT;
+    extern __shared__ double sOps[];
+    const int ncb = p.ncb, fb = p.fb;
+    const int offDrT = O::offDrT(ncb, fb), offDsT = O::offDsT(ncb, fb), offIT = O::offIT(ncb, fb),
+              offMass = FILTER ? O::offMF(ncb, fb) : O::offM(ncb, fb), offF = O::offF(ncb, fb);
+    if constexpr (OPSLDS) {
+        const int n = O::offGI(ncb, fb) * 64;
+        for (int t = threadIdx.x; t < n; t += blockDim.x) sOps[t] = p.ops[t];
+        __syncthreads();
+    }
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    auto A = [&](int tile) -> double {
+        if constexpr (OPSLDS) return sOps[tile * 64 + static_cast<int>(lane)];
+        else return p.ops[static_cast<size_t>(tile) * 64 + lane];
+    };
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, gplane = 48ll * fb * ld,
+                    cplane = 16ll * ncb * ld;
+    const double g = p.g;
+    const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u;
+    unsigned tile, tileEnd;
+    curved_wave_tiles(ntiles, tile, tileEnd);
+    for (; tile < tileEnd; ++tile) {
+        const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
+        const bool live = kTrue <= kLast;
+        const unsigned k = live ? kTrue : kLast; // padding lanes recompute the last element, store nothing
+        const unsigned k8 = k * 8u, k4 = k * 4u;
+
+        // ---- own nodal state in operand layout: node m = 4 t + q
+        double qB[4][KV];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const int m = 4 * t + static_cast<int>(q);
+                qB[c][t] = m < Np ? cld_row(p.qin + c * plane + m * ld, k8) : 0.0;
+            }
+
+        cmfma_t acc[4][MT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) acc[c][r] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+
+        // ---- volume term, 16 cubature points at a time
+        for (int rb = 0; rb < ncb; ++rb) {
+            cmfma_t cv[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cv[c] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const double a = A(rb * KV + t);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], cv[c], 0, 0, 0);
+            }
+            double tr[4][4], ts[4][4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * rb + static_cast<int>(q) + 4 * reg;
+                const long long ro = static_cast<long long>(row) * ld;
+                const double wrx = cld_row(p.cubG + ro, k8), wry = cld_row(p.cubG + cplane + ro, k8),
+                             wsx = cld_row(p.cubG + 2 * cplane + ro, k8), wsy = cld_row(p.cubG + 3 * cplane + ro, k8);
+                const bool valid = row < p.ncub;
+                const CurvedFlux fl = curved_fluxes(valid ? cv[0][reg] : 1.0, cv[1][reg], cv[2][reg], cv[3][reg], g);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    tr[c][reg] = wrx * fl.F[c] + wry * fl.G[c];
+                    ts[c][reg] = wsx * fl.F[c] + wsy * fl.G[c];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < MT; ++r)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const double aDr = A(offDrT + (r * ncb + rb) * 4 + reg), aDs = A(offDsT + (r * ncb + rb) * 4 + reg);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDr, tr[c][reg], acc[c][r], 0, 0, 0);
+                        acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDs, ts[c][reg], acc[c][r], 0, 0, 0);
+                    }
+                }
+        }
+
+        // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face
+        for (int f = 0; f < 3; ++f) {
+            double lam = 0.0;
+            for (int pass = 0; pass < 2; ++pass) { // pass 0: the face's maximum speed; pass 1: fluxes with it
+                for (int b = 0; b < fb; ++b) {
+                    const int gb = f * fb + b;
+                    double sflux[4][4];
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int local = 16 * b + static_cast<int>(q) + 4 * reg, gr = 16 * gb + static_cast<int>(q) + 4 * reg;
+                        const bool valid = local < p.ng;
+                        const long long go = static_cast<long long>(gr) * ld;
+                        const int idP = cld_row(p.gmapP + go, k4);
+                        const unsigned oP = static_cast<unsigned>(idP < 0 ? -(idP + 1) : idP) * 8u;
+                        const unsigned oM = p.gmapM ? static_cast<unsigned>(cld_row(p.gmapM + go, k4)) * 8u
+                                                    : static_cast<unsigned>(go) * 8u + k8;
+                        double hM = cld_row(p.gq, oM), huM = cld_row(p.gq + gplane, oM), hvM = cld_row(p.gq + 2 * gplane, oM),
+                               hNM = cld_row(p.gq + 3 * gplane, oM);
+                        double hP = cld_row(p.gq, oP), huP = cld_row(p.gq + gplane, oP), hvP = cld_row(p.gq + 2 * gplane, oP),
+                               hNP = cld_row(p.gq + 3 * gplane, oP);
+                        if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
+                        const double uM = huM / hM, uP = huP / hP, vM = hvM / hM, vP = hvP / hP; // before the wall condition (rhs.py:81-85)
+                        if (pass == 0) {
+                            const double spdM = sqrt(uM * uM + vM * vM) + sqrt(g * hM);
+                            const double spdP = sqrt(uP * uP + vP * vP) + sqrt(g * hP);
+                            lam = valid ? fmax(lam, fmax(spdM, spdP)) : lam;
+                        } else {
+                            const double nx = cld_row(p.gaussG + go, k8), ny = cld_row(p.gaussG + gplane + go, k8),
+                                         W = cld_row(p.gaussG + 2 * gplane + go, k8);
+                            if (idP < 0) { // reflective wall (rhs.py:87-88)
+                                const double un = huM * nx + hvM * ny;
+                                huP = huM - 2 * nx * un;
+                                hvP = hvM - 2 * ny * un;
+                            }
+                            const CurvedFlux fM = curved_fluxes(hM, huM, hvM, hNM, g), fP = curved_fluxes(hP, huP, hvP, hNP, g);
+                            const double dq[4] = {hM - hP, huM - huP, hvM - hvP, hNM - hNP};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                sflux[c][reg] = W * (0.5 * ((fM.F[c] + fP.F[c]) * nx + (fM.G[c] + fP.G[c]) * ny + lam * dq[c]));
+                        }
+                    }
+                    if (pass == 1) {
+#pragma unroll
+                        for (int r = 0; r < MT; ++r)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg) {
+                                const double a = A(offIT + (r * 3 * fb + gb) * 4 + reg);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c)
+                                    acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sflux[c][reg], acc[c][r], 0, 0, 0);
+                            }
+                    }
+                }
+                if (pass == 0) { // the face's Gauss points sit in the 4 lanes q of this element
+                    lam = fmax(lam, __shfl_xor(lam, 16));
+                    lam = fmax(lam, __shfl_xor(lam, 32));
+                }
+            }
+        }
+
+        // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
+        const int slot = p.curvedSlot ? cld_row(p.curvedSlot, k4) : -1;
+        cmfma_t out[4][MT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) out[c][r] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+        double S2[KV], S3[KV];
+#pragma unroll
+        for (int t = 0; t < KV; ++t) {
+            const int m = 4 * t + static_cast<int>(q);
+            S2[t] = S3[t] = 0.0;
+            double rj = 0.0;
+            if (m < Np) {
+                rj = cld_row(p.rJ + m * ld, k8);
+                curved_sources(p, qB[0][t], qB[1][t], qB[2][t], m * ld, k8, S2[t], S3[t]);
+            }
+#pragma unroll
+            for (int r = 0; r < MT; ++r) {
+                const double a = A(offMass + r * KV + t);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    out[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[c][t >> 2][t & 3] * rj, out[c][r], 0, 0, 0);
+                if constexpr (FILTER) {
+                    const double af = A(offF + r * KV + t);
+                    out[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S2[t], out[1][r], 0, 0, 0);
+                    out[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S3[t], out[2][r], 0, 0, 0);
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < KV; ++t) {
+                    const int m = 4 * t + static_cast<int>(q);
+                    if (m >= Np) continue;
+                    if (slot >= 0) { // element of curvedEls: its own mass matrix is applied by the fix-up kernel
+                        p.mmSide[(static_cast<long long>(c) * Np + m) * p.sideLd + slot] = acc[c][t >> 2][t & 3];
+                        continue;
+                    }
+                    double R = out[c][t >> 2][t & 3];
+                    if constexpr (!FILTER) R += c == 1 ? S2[t] : (c == 2 ? S3[t] : 0.0);
+                    const long long off = c * plane + m * ld;
+                    if constexpr (MODE == CMODE_RHS) {
+                        cst_row(p.rhs + off, k8, R);
+                    } else if constexpr (MODE == CMODE_LSERK) {
+                        const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * R;
+                        cst_row(p.res + off, k8, n1);
+                        cst_row(p.qout + off, k8, qB[c][t] + p.cb * n1);
+                    } else {
+                        cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * qB[c][t] + p.cc * R);
+                    }
+                }
+        }
+    }
+}
+
+// ---- elements of curvedEls: RHS_c = U^-1 U^-T MM_c with the element's own Cholesky factor (rhs.py:157-162), then
+// sources, filter and update as above. One lane per element; columns of the side buffers are contiguous.
+template <int N, int MODE, bool FILTER>
+__global__ __launch_bounds__(64) void sw2d_curved_fixup_kernel(const CurvedParams p) {
+    constexpr int Np = (N + 1) * (N + 2) / 2;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= p.numCurved) return;
+    const unsigned k = static_cast<unsigned>(p.curvedEls[slot]), k8 = k * 8u;
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, sld = p.sideLd;
+    const double* __restrict__ U = p.cholSide + slot; // U[i][j] at U[(i*Np + j) * sld]
+    double h[Np], hu[Np], hv[Np];
+#pragma unroll 1
+    for (int m = 0; m < Np; ++m) {
+        h[m] = cld_row(p.qin + m * ld, k8);
+        hu[m] = cld_row(p.qin + plane + m * ld, k8);
+        hv[m] = cld_row(p.qin + 2 * plane + m * ld, k8);
+    }
+    for (int c = 0; c < 4; ++c) {
+        double x[Np], r[Np];
+#pragma unroll 1
+        for (int m = 0; m < Np; ++m) x[m] = p.mmSide[(static_cast<long long>(c) * Np + m) * sld + slot];
+        // U^T y = b (forward), then U x = y (backward)
+#pragma unroll 1
+        for (int i = 0; i < Np; ++i) {
+            double s = x[i];
+            for (int jj = 0; jj < i; ++jj) s -= U[(static_cast<long long>(jj) * Np + i) * sld] * x[jj];
+            x[i] = s / U[(static_cast<long long>(i) * Np + i) * sld];
+        }
+#pragma unroll 1
+        for (int i = Np - 1; i >= 0; --i) {
+            double s = x[i];
+            for (int jj = i + 1; jj < Np; ++jj) s -= U[(static_cast<long long>(i) * Np + jj) * sld] * x[jj];
+            x[i] = s / U[(static_cast<long long>(i) * Np + i) * sld];
+        }
+        if (c == 1 || c == 2) {
+#pragma unroll 1
+            for (int m = 0; m < Np; ++m) {
+                double S2, S3;
+                curved_sources(p, h[m], hu[m], hv[m], m * ld, k8, S2, S3);
+                x[m] += c == 1 ? S2 : S3;
+            }
+        }
+        if constexpr (FILTER) {
+#pragma unroll 1
+            for (int i = 0; i < Np; ++i) {
+                double s = 0.0;
+                for (int m = 0; m < Np; ++m) s += p.filt[i * Np + m] * x[m];
+                r[i] = s;
+            }
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < Np; ++i) r[i] = x[i];
+        }
+#pragma unroll 1
+        for (int m = 0; m < Np; ++m) {
+            const long long off = c * plane + m * ld;
+            if constexpr (MODE == CMODE_RHS) {
+                cst_row(p.rhs + off, k8, r[m]);
+            } else if constexpr (MODE == CMODE_LSERK) {
+                const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * r[m];
+                cst_row(p.res + off, k8, n1);
+                cst_row(p.qout + off, k8, cld_row(p.qin + off, k8) + p.cb * n1);
+            } else {
+                cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * cld_row(p.qin + off, k8) + p.cc * r[m]);
+            }
+        }
+    }
+}
+
+// Launch table of one polynomial order (compiled per order in sw2d_curved_order.hip).
+struct CurvedKernelTable {
+    int order, Np, KV, MT;
+    int (*opsTiles)(int ncb, int fb);                 // tiles of the whole image
+    int (*stageTiles)(int ncb, int fb);               // tiles the stage kernel stages in LDS
+    void (*opsOffsets)(int ncb, int fb, int* off);    // offVc, offDrT, offDsT, offIT, offM, offMF, offF, offGI
+    hipError_t (*gauss)(const CurvedParams& p, hipStream_t stream);
+    hipError_t (*stage)(int mode, bool filter, const CurvedParams& p, hipStream_t stream);
+    hipError_t (*fixup)(int mode, bool filter, const CurvedParams& p, hipStream_t stream);
+};
+const CurvedKernelTable* curved_kernel_table(int order); // nullptr if the order is not compiled in
+
+} // namespace bdg_dev

@@ -1,0 +1,89 @@
+// Instantiates the curved / over-integrated sw2d kernels for one polynomial order (-DBDG_ORDER=N).
+#include "sw2d_curved_kernel.hpp"
+#include <algorithm>
+
+#ifndef BDG_ORDER
+#error "compile with -DBDG_ORDER=<polynomial order>"
+#endif
+
+namespace bdg_dev {
+namespace {
+
+constexpr int kN = BDG_ORDER;
+using O = CurvedOps<kN>;
+// Dynamic LDS a workgroup of the stage kernel may claim for the operator image; beyond it the tiles are read
+// from global memory (they stay in L1 / L2: every wave reads the same image).
+constexpr int kLdsBudgetBytes = 150 * 1024;
+
+int opsTiles(int ncb, int fb) { return O::tiles(ncb, fb); }
+int stageTiles(int ncb, int fb) { return O::offGI(ncb, fb); }
+void opsOffsets(int ncb, int fb, int* off) {
+    off[0] = O::offVc(ncb, fb); off[1] = O::offDrT(ncb, fb); off[2] = O::offDsT(ncb, fb); off[3] = O::offIT(ncb, fb);
+    off[4] = O::offM(ncb, fb); off[5] = O::offMF(ncb, fb); off[6] = O::offF(ncb, fb); off[7] = O::offGI(ncb, fb);
+}
+
+unsigned gridFor(int K, int wgPerCu) {
+    const unsigned ntiles = (static_cast<unsigned>(K) + 15u) / 16u, wgs = (ntiles + 3u) / 4u;
+    return std::max(1u, std::min(wgs, 256u * static_cast<unsigned>(wgPerCu) * 2u));
+}
+
+hipError_t gauss(const CurvedParams& p, hipStream_t stream) {
+    if (p.K < 1) return hipSuccess;
+    const size_t lds = static_cast<size_t>(3) * p.fb * O::KV * 64 * sizeof(double);
+    hipLaunchKernelGGL((sw2d_curved_gauss_kernel<kN>), dim3(gridFor(p.K, 4)), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int MODE, bool FILTER>
+hipError_t launchStage(const CurvedParams& p, hipStream_t stream) {
+    if (p.K < 1) return hipSuccess;
+    const size_t lds = static_cast<size_t>(O::offGI(p.ncb, p.fb)) * 64 * sizeof(double);
+    if (lds <= static_cast<size_t>(kLdsBudgetBytes)) {
+        auto kern = sw2d_curved_stage_kernel<kN, MODE, FILTER, true>;
+        if (lds > 64 * 1024) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+        }
+        const int wgPerCu = std::max(1, static_cast<int>(160 * 1024 / std::max<size_t>(lds, 1)));
+        hipLaunchKernelGGL(kern, dim3(gridFor(p.K, std::min(wgPerCu, 2))), dim3(256), lds, stream, p);
+    } else {
+        hipLaunchKernelGGL((sw2d_curved_stage_kernel<kN, MODE, FILTER, false>), dim3(gridFor(p.K, 2)), dim3(256), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t stage(int mode, bool filter, const CurvedParams& p, hipStream_t stream) {
+    switch (mode) {
+    case CMODE_RHS: return filter ? launchStage<CMODE_RHS, true>(p, stream) : launchStage<CMODE_RHS, false>(p, stream);
+    case CMODE_LSERK: return filter ? launchStage<CMODE_LSERK, true>(p, stream) : launchStage<CMODE_LSERK, false>(p, stream);
+    case CMODE_COMBINE: return filter ? launchStage<CMODE_COMBINE, true>(p, stream) : launchStage<CMODE_COMBINE, false>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <int MODE, bool FILTER>
+hipError_t launchFixup(const CurvedParams& p, hipStream_t stream) {
+    if (p.numCurved < 1) return hipSuccess;
+    hipLaunchKernelGGL((sw2d_curved_fixup_kernel<kN, MODE, FILTER>), dim3((p.numCurved + 63) / 64), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t fixup(int mode, bool filter, const CurvedParams& p, hipStream_t stream) {
+    switch (mode) {
+    case CMODE_RHS: return filter ? launchFixup<CMODE_RHS, true>(p, stream) : launchFixup<CMODE_RHS, false>(p, stream);
+    case CMODE_LSERK: return filter ? launchFixup<CMODE_LSERK, true>(p, stream) : launchFixup<CMODE_LSERK, false>(p, stream);
+    case CMODE_COMBINE: return filter ? launchFixup<CMODE_COMBINE, true>(p, stream) : launchFixup<CMODE_COMBINE, false>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+const CurvedKernelTable kTable = {kN, O::Np, O::KV, O::MT, opsTiles, stageTiles, opsOffsets, gauss, stage, fixup};
+
+} // namespace
+
+#define BDG_CAT2(a, b) a##b
+#define BDG_CAT(a, b) BDG_CAT2(a, b)
+const CurvedKernelTable* BDG_CAT(curved_kernel_table_order, BDG_ORDER)() { return &kTable; }
+
+} // namespace bdg_dev

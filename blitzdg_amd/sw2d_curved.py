@@ -1,0 +1,127 @@
+"""Curved / over-integrated sw2d on the MI355X: host-side mirror of the reference's curved RHS path.
+
+``Sw2dCurvedSolver`` wraps the ``bdg_sw2d_curved_*`` C ABI (include/blitzdg_hip.h): every table the reference's
+``swhelpers.rhs.sw2dComputeRHS_curved`` (swhelpers/rhs.py:6-176) reads from its context arguments is an input.
+``examples``-style use, the reference driver's loop (sw2d_curved.py:246-277) with the state resident::
+
+    solver = Sw2dCurvedSolver(ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP, g=g, zx=zx, zy=zy, f=f, CD=CD)
+    solver.setState(h, hu, hv, hN)
+    solver.stepRK2(dt, nsteps, filter=True)
+    h, hu, hv, hN = solver.getState()
+
+There is no CPU fallback: without the HIP library / a GPU, construction raises.
+"""
+import numpy as np
+
+from . import _capi as C
+from ._capi import byref, c_float, c_void_p, check, lib
+
+
+class Sw2dCurvedSolver:
+    def __init__(self, ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP, g=9.81, zx=None, zy=None, f=0.0, CD=0.0,
+                 device=0):
+        """ctx: DGContext2D-like (V, numLocalPoints, numElements, optional filter); cub_ctx: V, Dr, Ds, W, rx, ry, sx,
+        sy, MMChol; gauss_ctx: Interp, W, nx, ny, BCmap (tag 3 = reflective wall); J: (Np, K) nodal Jacobian;
+        gmapM / gmapP: flat Gauss-node maps; f and CD: scalars or (Np, K) arrays."""
+        Np, K = int(ctx.numLocalPoints), int(ctx.numElements)
+        order = int(round((np.sqrt(8 * Np + 1) - 3) / 2))
+        if (order + 1) * (order + 2) // 2 != Np:
+            raise ValueError(f"numLocalPoints = {Np} is not a triangle node count")
+        cubV = C.as_f64(cub_ctx.V)
+        Ncub = cubV.shape[0]
+        gI = C.as_f64(gauss_ctx.Interp)
+        if gI.shape[0] % 3:
+            raise ValueError("gauss_ctx.Interp must have 3*NGauss rows")
+        NG = gI.shape[0] // 3
+        keep = []  # arrays must outlive the create call
+
+        def f64(a, shape, name):
+            arr = C.as_f64(a, shape, name)
+            keep.append(arr)
+            return C.ptr(arr)
+
+        def i32(a, n, name):
+            arr = C.as_i32(np.asarray(a).reshape(-1))
+            if n is not None and arr.size != n:
+                raise ValueError(f"{name}: expected {n} entries, got {arr.size}")
+            keep.append(arr)
+            return C.ptr(arr) if arr.size else None, arr.size
+
+        filt = getattr(ctx, "filter", None)
+        d = C.Sw2dCurvedDesc()
+        d.order, d.num_elements, d.num_cub, d.num_gauss = order, K, Ncub, NG
+        d.V = f64(ctx.V, (Np, Np), "ctx.V")
+        d.Filter = f64(filt, (Np, Np), "ctx.filter") if filt is not None and np.size(filt) == Np * Np else None
+        d.J = f64(J, (Np, K), "J")
+        d.cubV = f64(cubV, (Ncub, Np), "cub_ctx.V")
+        d.cubDr, d.cubDs = f64(cub_ctx.Dr, (Ncub, Np), "cub_ctx.Dr"), f64(cub_ctx.Ds, (Ncub, Np), "cub_ctx.Ds")
+        for name in ("W", "rx", "ry", "sx", "sy"):
+            setattr(d, "cub" + name, f64(getattr(cub_ctx, name), (Ncub, K), "cub_ctx." + name))
+        d.gaussInterp = f64(gI, (3 * NG, Np), "gauss_ctx.Interp")
+        d.gaussW, d.gaussnx, d.gaussny = (f64(getattr(gauss_ctx, n), (3 * NG, K), "gauss_ctx." + n) for n in ("W", "nx", "ny"))
+        d.gmapM, _ = i32(gmapM, 3 * NG * K, "gmapM")
+        d.gmapP, _ = i32(gmapP, 3 * NG * K, "gmapP")
+        d.gmapW, d.num_wall = i32(gauss_ctx.BCmap.get(3, []), None, "gauss_ctx.BCmap[3]")
+        d.curvedEls, d.num_curved = i32(list(curvedEls), None, "curvedEls")
+        d.MMChol = f64(cub_ctx.MMChol, (Np, Np, K), "cub_ctx.MMChol") if d.num_curved else None
+        d.zx = f64(zx, (Np, K), "zx") if zx is not None else None
+        d.zy = f64(zy, (Np, K), "zy") if zy is not None else None
+        if np.ndim(f) == 0:
+            d.coriolis, d.coriolis_const = None, float(f)
+        else:
+            d.coriolis, d.coriolis_const = f64(f, (Np, K), "f"), 0.0
+        if np.ndim(CD) == 0:
+            d.drag, d.drag_const = None, float(CD)
+        else:
+            d.drag, d.drag_const = f64(CD, (Np, K), "CD"), 0.0
+        d.g, d.device, d.flags = float(g), int(device), 0
+        h = c_void_p()
+        check(lib.bdg_sw2d_curved_create(byref(d), byref(h)))
+        self._h = h
+        self.Np, self.K, self.order, self.Ncub, self.NGauss = Np, K, order, Ncub, NG
+        self.hasFilter = d.Filter is not None
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.bdg_sw2d_curved_destroy(h)
+
+    close = __del__
+
+    def _fields(self, arrays, names=("h", "hu", "hv", "hN")):
+        return [C.as_f64(a, (self.Np, self.K), n) for a, n in zip(arrays, names)]
+
+    def computeRHS(self, h, hu, hv, hN, filter=False):
+        """(RHS1, RHS2, RHS3, RHS4) of the reference function for host fields (upload, three kernels, download)."""
+        q = self._fields((h, hu, hv, hN))
+        out = [np.empty((self.Np, self.K)) for _ in range(4)]
+        check(lib.bdg_sw2d_curved_rhs(self._h, *[C.ptr(a) for a in q], *[C.ptr(o) for o in out], int(bool(filter))))
+        return tuple(out)
+
+    def setState(self, h, hu, hv, hN):
+        q = self._fields((h, hu, hv, hN))
+        check(lib.bdg_sw2d_curved_set_state(self._h, *[C.ptr(a) for a in q]))
+
+    def getState(self):
+        out = [np.empty((self.Np, self.K)) for _ in range(4)]
+        check(lib.bdg_sw2d_curved_get_state(self._h, *[C.ptr(o) for o in out]))
+        return tuple(out)
+
+    def stepRK2(self, dt, nsteps=1, filter=True):
+        """The reference driver's loop body (sw2d_curved.py:246-277), nsteps times, state resident."""
+        check(lib.bdg_sw2d_curved_step_rk2(self._h, float(dt), int(nsteps), int(bool(filter))))
+
+    def lserk4Stages(self, dt, nstages):
+        check(lib.bdg_sw2d_curved_lserk4_stages(self._h, float(dt), int(nstages)))
+
+    def timeRK2(self, dt, nsteps, filter=True):
+        """Milliseconds per RHS evaluation (HIP events on the solver's stream), averaged over 2*nsteps."""
+        ms = c_float()
+        check(lib.bdg_sw2d_curved_time_rk2(self._h, float(dt), int(nsteps), int(bool(filter)), byref(ms)))
+        return ms.value
+
+    def synchronize(self):
+        check(lib.bdg_sw2d_curved_synchronize(self._h))
+
+    deviceBytes = property(lambda self: lib.bdg_sw2d_curved_device_bytes(self._h))
+    bytesPerElement = property(lambda self: lib.bdg_sw2d_curved_bytes_per_element(self._h))

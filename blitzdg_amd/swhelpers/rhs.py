@@ -11,8 +11,34 @@ sy, Dr, Ds, numFacePoints, numElements, numFaces, Lift, Fscale).
 import numpy as np
 
 from ..sw2d import Sw2dSolver
+from ..sw2d_curved import Sw2dCurvedSolver
 
 _cache = {}
+_curved_cache = {}
+
+
+def sw2dComputeRHS_curved(h, hu, hv, hN, zx, zy, g, H, f, CD, ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP):
+    """The reference's curved / over-integrated RHS, same 17 arguments (swhelpers/rhs.py:6):
+
+        sw2dComputeRHS_curved(h, hu, hv, hN, zx, zy, g, H, f, CD, ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP)
+            -> (RHS1, RHS2, RHS3, RHS4)
+
+    evaluated on the MI355X through the C ABI (bdg_sw2d_curved_*). ``H`` is accepted and, as in the reference
+    (rhs.py:16, :73-75: cub_H and gauss_H are formed and never used), does not enter the result. The device
+    image of the context tables is cached per set of argument objects (like the reference, the tables are read
+    as they are at the first call with these objects)."""
+    fkey = float(f) if np.ndim(f) == 0 else id(f)
+    ckey = float(CD) if np.ndim(CD) == 0 else id(CD)
+    key = (id(ctx), id(cub_ctx), id(gauss_ctx), id(curvedEls), id(J), id(gmapM), id(gmapP), id(zx), id(zy), float(g),
+           fkey, ckey)
+    entry = _curved_cache.get(key)
+    if entry is None:
+        solver = Sw2dCurvedSolver(ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP, g=g, zx=zx, zy=zy, f=f, CD=CD)
+        entry = (solver, (ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP, zx, zy, f, CD))  # keeps the ids alive
+        if len(_curved_cache) >= 4:
+            _curved_cache.pop(next(iter(_curved_cache)))
+        _curved_cache[key] = entry
+    return entry[0].computeRHS(h, hu, hv, hN)
 
 
 def _key(ctx, vmapM, vmapP, zx, zy, g, f, CD):

@@ -375,6 +375,66 @@ size_t bdg_sw2d_device_bytes(const bdg_sw2d* s);
 /* The raw stream (hipStream_t) launches are issued on, for callers that interleave their own work. */
 void* bdg_sw2d_stream(bdg_sw2d* s);
 
+/* ---------------------------------------------------------------- sw2d, curved / over-integrated RHS
+ * reference: swhelpers.rhs.sw2dComputeRHS_curved(h, hu, hv, hN, zx, zy, g, H, f, CD, ctx, cub_ctx, gauss_ctx,
+ * curvedEls, J, gmapM, gmapP) (swhelpers/rhs.py:6-176), driven by sw2d_curved.py:246-277 (RHS, Filter, midpoint
+ * RK2). The function is pure in its context arguments, and so is this solver: every table is an input (any
+ * cubature rule, any Gauss-node map -- periodic rewiring included), borrowed for the duration of create.
+ * Four fields always (h, hu, hv, hN). H is an argument of the reference function that it never uses
+ * (rhs.py:16, :73-75 form cub_H / gauss_H and drop them); it is therefore not part of this interface.
+ * Host code above this seam: blitzdg_amd/swhelpers/rhs.py (same 17-argument signature). */
+typedef struct bdg_sw2d_curved bdg_sw2d_curved;
+typedef struct bdg_sw2d_curved_desc {
+    int order;            /* N: 1..8                                                          */
+    int num_elements;     /* K                                                                */
+    int num_cub;          /* cubature points per element (cub_ctx.V.shape[0])                 */
+    int num_gauss;        /* Gauss points per face (gauss_ctx.NGauss)                         */
+    const double* V;      /* (Np, Np) ctx.V: the straight elements' mass inverse is V V^T     */
+    const double* Filter; /* (Np, Np) ctx.filter or NULL                                      */
+    const double* J;      /* (Np, K) nodal Jacobian as the driver forms it (sw2d_curved.py:112-118) */
+    const double* cubV; const double* cubDr; const double* cubDs;     /* (Ncub, Np) cub_ctx.V, Dr, Ds   */
+    const double* cubW; const double* cubrx; const double* cubry;     /* (Ncub, K)  cub_ctx.W, rx, ry   */
+    const double* cubsx; const double* cubsy;                         /* (Ncub, K)  cub_ctx.sx, sy      */
+    const double* gaussInterp;                                        /* (3 NGauss, Np) gauss_ctx.Interp */
+    const double* gaussW; const double* gaussnx; const double* gaussny; /* (3 NGauss, K) gauss_ctx.W, nx, ny */
+    const int* gmapM;     /* (3 NGauss K) flat Gauss ids g + 3 NGauss k                       */
+    const int* gmapP;
+    const int* gmapW;     /* gauss_ctx.BCmap[3]: flat ids of reflective-wall Gauss nodes      */
+    int num_wall;
+    const int* curvedEls; /* elements that take their own cubature mass matrix                */
+    int num_curved;
+    const double* MMChol; /* (Np, Np, K) cub_ctx.MMChol; only the columns of curvedEls are read; may be NULL if none */
+    const double* zx;     /* (Np, K) or NULL (= 0)                                            */
+    const double* zy;
+    const double* coriolis; /* (Np, K) f, or NULL: coriolis_const                             */
+    double coriolis_const;
+    const double* drag;   /* (Np, K) CD (an array in sw2d_curved.py:176-192), or NULL: drag_const */
+    double drag_const;
+    double g;
+    int device;
+    int flags;            /* 0                                                                */
+} bdg_sw2d_curved_desc;
+int bdg_sw2d_curved_create(const bdg_sw2d_curved_desc* desc, bdg_sw2d_curved** out);
+void bdg_sw2d_curved_destroy(bdg_sw2d_curved* s);
+/* The reference function itself: host (Np, K) fields in, host RHS out; filter != 0 returns Filter * RHS
+ * (what the driver applies next, sw2d_curved.py:250-253). The resident state is not disturbed. */
+int bdg_sw2d_curved_rhs(bdg_sw2d_curved* s, const double* h, const double* hu, const double* hv, const double* hN,
+                        double* rhs1, double* rhs2, double* rhs3, double* rhs4, int filter);
+int bdg_sw2d_curved_set_state(bdg_sw2d_curved* s, const double* h, const double* hu, const double* hv, const double* hN);
+int bdg_sw2d_curved_get_state(bdg_sw2d_curved* s, double* h, double* hu, double* hv, double* hN);
+/* num_steps of the driver's loop body (sw2d_curved.py:246-277) on the resident state: RHS, filter, predictor
+ * q1 = q + dt/2 RHS, RHS(q1), filter, corrector q += dt RHS. */
+int bdg_sw2d_curved_step_rk2(bdg_sw2d_curved* s, double dt, int num_steps, int filter);
+/* num_stages fused LSERK4 stages on the resident state (stage index continues across calls). */
+int bdg_sw2d_curved_lserk4_stages(bdg_sw2d_curved* s, double dt, int num_stages);
+/* As step_rk2, timed with HIP events on the solver's stream: milliseconds per RHS evaluation
+ * (Gauss-trace kernel + stage kernel + curved-element kernel), two evaluations per step. */
+int bdg_sw2d_curved_time_rk2(bdg_sw2d_curved* s, double dt, int num_steps, int filter, float* ms_per_rhs);
+int bdg_sw2d_curved_synchronize(bdg_sw2d_curved* s);
+size_t bdg_sw2d_curved_device_bytes(const bdg_sw2d_curved* s);
+/* Compulsory HBM bytes of one RHS evaluation with the tables as this solver holds them (per element, averaged). */
+double bdg_sw2d_curved_bytes_per_element(const bdg_sw2d_curved* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,195 @@
+"""Parity of the curved / over-integrated HIP path (bdg_sw2d_curved_*, through the C ABI) against
+  (a) the outputs of the reference's swhelpers.rhs.sw2dComputeRHS_curved stored in
+      tests/golden/sw2d_rhs_curved_*.npz (N = 2, 3, 4, 6, 8; curvedEls a strict subset of the elements; one case
+      with curvedEls a subset of the deformed elements; one with a periodic rewiring of gmapP),
+  (b) the NumPy restatement (oracle/oracle_np.py::sw2d_rhs_curved, bit-identical to (a)) on larger seeded inputs
+      and through the time loop of the reference's driver (sw2d_curved.py:246-277).
+Tolerance (fp64): the kernels evaluate the same contractions in another summation order (4-deep MFMA steps,
+fused multiply-adds, W*rx folded once): single RHS <= 1e-12 of max|RHS|, states after 20 steps <= 1e-11.
+"""
+import glob
+import os
+import types
+
+import numpy as np
+import pytest
+
+import blitzdg_amd.pyblitzdg as dg
+from blitzdg_amd._capi import BdgError
+from blitzdg_amd.sw2d_curved import Sw2dCurvedSolver
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+RHS_TOL = 1e-12
+STATE_TOL = 1e-11
+CURVED = sorted(glob.glob(os.path.join(GOLDEN, "sw2d_rhs_curved_*.npz")))
+IDS = [os.path.basename(p)[16:-4] for p in CURVED]
+
+
+def contexts_from_fixture(d):
+    ctx = types.SimpleNamespace(numLocalPoints=d["V"].shape[0], numElements=d["J"].shape[1], V=d["V"], filter=d["Filter"])
+    cub = types.SimpleNamespace(V=d["cubV"], Dr=d["cubDr"], Ds=d["cubDs"], W=d["cubW"], rx=d["cubrx"], ry=d["cubry"],
+                                sx=d["cubsx"], sy=d["cubsy"], MMChol=d["MMChol"])
+    gauss = types.SimpleNamespace(Interp=d["gInterp"], W=d["gW"], nx=d["gnx"], ny=d["gny"],
+                                  BCmap={3: [int(i) for i in d["gmapW"]]})
+    return ctx, cub, gauss
+
+
+def solver_from_fixture(d):
+    ctx, cub, gauss = contexts_from_fixture(d)
+    return Sw2dCurvedSolver(ctx, cub, gauss, d["curvedEls"], d["J"], d["gmapM"], d["gmapP"], g=float(d["g"]),
+                            zx=d["zx"], zy=d["zy"], f=float(d["f"]), CD=d["CD"])
+
+
+def relerr(got, ref):
+    scale = max(np.abs(r).max() for r in ref)
+    return max(np.abs(a - b).max() for a, b in zip(got, ref)) / scale
+
+
+@pytest.mark.parametrize("path", CURVED, ids=IDS)
+def test_curved_rhs_matches_the_reference_function(path):
+    d = np.load(path)
+    s = solver_from_fixture(d)
+    ref = [d[f"rhs{i}"] for i in (1, 2, 3, 4)]
+    got = s.computeRHS(d["h"], d["hu"], d["hv"], d["hN"])
+    assert relerr(got, ref) < RHS_TOL
+    curved = set(int(k) for k in d["curvedEls"])
+    assert 0 < len(curved) < d["J"].shape[1]                      # both mass-matrix branches are exercised
+    # the driver's next step, Filter * RHS (sw2d_curved.py:250-253), fused into the kernels
+    gotf = s.computeRHS(d["h"], d["hu"], d["hv"], d["hN"], filter=True)
+    assert relerr(gotf, [d["Filter"] @ r for r in ref]) < RHS_TOL
+
+
+def test_drop_in_signature_of_the_reference_function():
+    """blitzdg_amd.swhelpers.rhs.sw2dComputeRHS_curved takes the reference's 17 arguments (swhelpers/rhs.py:6) and
+    objects with the reference contexts' attribute names -- here real contexts from this repo's builders."""
+    from blitzdg_amd.swhelpers.rhs import sw2dComputeRHS_curved
+    d = np.load(os.path.join(GOLDEN, "sw2d_rhs_curved_coarse_box_N4.npz"))
+    mesh = dg.MeshManager()
+    mesh.readMesh(os.path.join(GOLDEN, "coarse_box.msh"))
+    nodes = dg.TriangleNodesProvisioner(4, mesh)
+    nodes.buildFilter(0.9 * 4, 4)
+    ctx = nodes.dgContext()
+    nodes.setCoordinates(d["x"], d["y"])
+    gauss_ctx = nodes.buildGaussFaceNodes(2 * (4 + 1))
+    cub_ctx = nodes.buildCubatureVolumeMesh(3 * (4 + 1))
+    J = d["J"]
+    gmapM, gmapP = gauss_ctx.mapM, gauss_ctx.mapP
+    H = d["H"]
+    curvedEls = [int(k) for k in d["curvedEls"]]
+    r = sw2dComputeRHS_curved(d["h"], d["hu"], d["hv"], d["hN"], d["zx"], d["zy"], float(d["g"]), H, float(d["f"]), d["CD"],
+                              ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP)
+    assert relerr(r, [d[f"rhs{i}"] for i in (1, 2, 3, 4)]) < RHS_TOL
+    r2 = sw2dComputeRHS_curved(d["h"], 2 * d["hu"], d["hv"], d["hN"], d["zx"], d["zy"], float(d["g"]), H, float(d["f"]),
+                               d["CD"], ctx, cub_ctx, gauss_ctx, curvedEls, J, gmapM, gmapP)   # cached device image
+    assert relerr(r2, r) > 1e-3
+
+
+def big_problem(order, nx, ny, seed=7):
+    """A deformed box with many elements, contexts from this repo's builders, and the oracle's tables."""
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(nx, ny)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    ctx = nodes.dgContext()
+    x0, y0 = ctx.x, ctx.y
+    rho2 = ((x0 - 0.4) ** 2 + (y0 + 1.0) ** 2) / 0.8 ** 2
+    b = np.where(rho2 < 1.0, (1.0 - rho2) ** 3, 0.0)
+    x, y = x0 + 0.02 * b * np.cos(1.3 * y0), y0 + 0.05 * b * np.sin(1.7 * x0 + 0.4)
+    curvedEls = np.where((np.abs(x - x0) + np.abs(y - y0)).max(axis=0) > 0)[0].astype(np.int32)
+    nodes.setCoordinates(x, y)
+    J = (ctx.Dr @ x) * (ctx.Ds @ y) - (ctx.Ds @ x) * (ctx.Dr @ y)
+    gauss = nodes.buildGaussFaceNodes(2 * (order + 1))
+    cub = nodes.buildCubatureVolumeMesh(3 * (order + 1))
+    rng = np.random.default_rng(seed)
+    h = 1.0 + 0.3 * np.exp(-8 * x * x - 8 * y * y)
+    hu, hv = 0.05 * rng.standard_normal(x.shape), 0.05 * rng.standard_normal(x.shape)
+    hN = h * (0.5 + 0.3 * np.sin(2 * x) * np.cos(3 * y))
+    zx, zy = 0.05 + 0 * x, -0.04 * y
+    CD = 2.5e-3 * (1.0 + 0.5 * np.cos(x))
+    t = dict(cubV=cub.V, cubDr=cub.Dr, cubDs=cub.Ds, cubW=cub.W, cubrx=cub.rx, cubry=cub.ry, cubsx=cub.sx, cubsy=cub.sy,
+             gInterp=gauss.Interp, gW=gauss.W, gnx=gauss.nx, gny=gauss.ny, gmapM=gauss.mapM, gmapP=gauss.mapP,
+             gmapW=np.array(gauss.BCmap[3], dtype=np.int32), V=ctx.V, J=J, MMChol=cub.MMChol, curvedEls=curvedEls,
+             Filter=ctx.filter)
+    solver = Sw2dCurvedSolver(ctx, cub, gauss, curvedEls, J, gauss.mapM, gauss.mapP, g=0.0245, zx=zx, zy=zy, f=0.0788, CD=CD)
+    return solver, t, (h, hu, hv, hN), dict(zx=zx, zy=zy, g=0.0245, f=0.0788, CD=CD)
+
+
+@pytest.mark.parametrize("order,nx,ny", [(1, 23, 17), (4, 40, 33), (5, 21, 16), (7, 9, 8)])
+def test_curved_rhs_matches_the_oracle_on_ragged_meshes(order, nx, ny):
+    """Element counts that are not a multiple of the 16-element tile or of the 64-element padding."""
+    from oracle import oracle_np
+    s, t, q, ph = big_problem(order, nx, ny)
+    ref = oracle_np.sw2d_rhs_curved(*q, ph["zx"], ph["zy"], ph["g"], ph["f"], ph["CD"], t)
+    assert relerr(s.computeRHS(*q), ref) < RHS_TOL
+    assert 0 < len(t["curvedEls"]) < 2 * nx * ny
+
+
+def test_driver_loop_rk2_with_filter_matches_the_oracle():
+    """sw2d_curved.py:246-277 -- RHS, filter, predictor, RHS, filter, corrector -- 20 steps resident on the device
+    against the same loop in NumPy on the oracle."""
+    from oracle import oracle_np
+    s, t, q, ph = big_problem(3, 12, 10)
+    dt, Filt = 2e-3, t["Filter"]
+    s.setState(*q)
+    s.stepRK2(dt, 20, filter=True)
+    got = s.getState()
+    ref = [a.copy() for a in q]
+    rhs = lambda qq: [Filt @ r for r in oracle_np.sw2d_rhs_curved(*qq, ph["zx"], ph["zy"], ph["g"], ph["f"], ph["CD"], t)]  # noqa: E731
+    for _ in range(20):
+        r = rhs(ref)
+        q1 = [a + 0.5 * dt * b for a, b in zip(ref, r)]
+        r = rhs(q1)
+        ref = [a + dt * b for a, b in zip(ref, r)]
+    assert relerr(got, ref) < STATE_TOL
+    assert np.abs(ref[1] - q[1]).max() > 1e-4                    # the state did move
+    # LSERK4 stages on the same state: 5 stages = one step of the reference's low-storage scheme (include/LSERK4.hpp)
+    a = dg.LSERK4.rk4a
+    bcoef = dg.LSERK4.rk4b
+    s.setState(*q)
+    s.lserk4Stages(dt, 5)
+    got = s.getState()
+    ref, res = [x.copy() for x in q], [np.zeros_like(x) for x in q]
+    for i in range(5):
+        r = oracle_np.sw2d_rhs_curved(*ref, ph["zx"], ph["zy"], ph["g"], ph["f"], ph["CD"], t)
+        res = [a[i] * x + dt * y for x, y in zip(res, r)]
+        ref = [x + bcoef[i] * y for x, y in zip(ref, res)]
+    assert relerr(got, ref) < STATE_TOL
+
+
+def test_straight_mesh_without_curved_elements_and_constant_sources():
+    """curvedEls empty, scalar f and CD, no bed slope, identity maps: the plain over-integrated RHS."""
+    from oracle import oracle_np
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(7, 5, shuffleSeed=99)
+    nodes = dg.TriangleNodesProvisioner(4, mesh)
+    ctx = nodes.dgContext()
+    gauss, cub = nodes.buildGaussFaceNodes(10), nodes.buildCubatureVolumeMesh(15)
+    x, y = ctx.x, ctx.y
+    rng = np.random.default_rng(11)
+    h = 2.0 + 0.3 * np.sin(2 * x) * np.cos(y)
+    hu, hv = 0.2 * rng.standard_normal(x.shape), 0.2 * rng.standard_normal(x.shape)
+    hN = 0.7 * h
+    s = Sw2dCurvedSolver(ctx, cub, gauss, [], ctx.J, gauss.mapM, gauss.mapP, g=9.81, f=1e-2, CD=3e-3)
+    t = dict(cubV=cub.V, cubDr=cub.Dr, cubDs=cub.Ds, cubW=cub.W, cubrx=cub.rx, cubry=cub.ry, cubsx=cub.sx, cubsy=cub.sy,
+             gInterp=gauss.Interp, gW=gauss.W, gnx=gauss.nx, gny=gauss.ny, gmapM=gauss.mapM, gmapP=gauss.mapP,
+             gmapW=np.array(gauss.BCmap[3], dtype=np.int32), V=ctx.V, J=ctx.J, MMChol=cub.MMChol, curvedEls=[])
+    z = np.zeros_like(h)
+    ref = oracle_np.sw2d_rhs_curved(h, hu, hv, hN, z, z, 9.81, 1e-2, 3e-3, t)
+    assert relerr(s.computeRHS(h, hu, hv, hN), ref) < RHS_TOL
+    with pytest.raises(BdgError, match="Filter"):
+        s.computeRHS(h, hu, hv, hN, filter=True)                 # ctx.filter was never built
+
+
+def test_bad_tables_are_refused_before_anything_runs():
+    d = np.load(CURVED[0])
+    ctx, cub, gauss = contexts_from_fixture(d)
+    bad = d["gmapP"].copy()
+    bad[5] = bad.size                                            # one past the last Gauss node
+    with pytest.raises(BdgError, match="out of range"):
+        Sw2dCurvedSolver(ctx, cub, gauss, d["curvedEls"], d["J"], d["gmapM"], bad, g=1.0)
+    with pytest.raises(BdgError, match="curvedEls"):
+        Sw2dCurvedSolver(ctx, cub, gauss, [d["J"].shape[1]], d["J"], d["gmapM"], d["gmapP"], g=1.0)
+    with pytest.raises(BdgError, match="positive"):
+        Sw2dCurvedSolver(ctx, cub, gauss, d["curvedEls"], -d["J"], d["gmapM"], d["gmapP"], g=1.0)
