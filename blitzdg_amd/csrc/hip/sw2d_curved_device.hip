@@ -153,6 +153,7 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
     const bdg_dev::CurvedKernelTable* kt = bdg_dev::curved_kernel_table(d.order);
     if (!kt) throw arg_error("bdg_sw2d_curved_create: order must be 1..8");
     if (d.num_elements < 1 || d.num_cub < 1 || d.num_gauss < 1) throw arg_error("bdg_sw2d_curved_create: bad sizes");
+    if (d.num_gauss > 32) throw arg_error("bdg_sw2d_curved_create: at most 32 Gauss points per face");
     if (!d.V || !d.J || !d.cubV || !d.cubDr || !d.cubDs || !d.cubW || !d.cubrx || !d.cubry || !d.cubsx || !d.cubsy ||
         !d.gaussInterp || !d.gaussW || !d.gaussnx || !d.gaussny || !d.gmapM || !d.gmapP)
         throw arg_error("bdg_sw2d_curved_create: a required table pointer is NULL");
@@ -295,8 +296,10 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
             for (int i = 0; i < Np; ++i) {
                 for (int jj = 0; jj < Np; ++jj)
                     chol[(static_cast<size_t>(i) * Np + jj) * sld + c] = d.MMChol[(static_cast<size_t>(i) * Np + jj) * K + curved[c]];
-                if (!(d.MMChol[(static_cast<size_t>(i) * Np + i) * K + curved[c]] > 0.0))
+                const double dii = d.MMChol[(static_cast<size_t>(i) * Np + i) * K + curved[c]];
+                if (!(dii > 0.0))
                     throw arg_error("bdg_sw2d_curved_create: MMChol has a non-positive diagonal entry on an element of curvedEls");
+                chol[(static_cast<size_t>(i) * Np + i) * sld + c] = 1.0 / dii; // the solves multiply by 1 / U_ii
             }
         s->cholSide.alloc(chol.size(), s->bytes, st);
         hipOk(hipMemcpyAsync(s->cholSide.p, chol.data(), chol.size() * sizeof(double), hipMemcpyHostToDevice, st), "chol upload");

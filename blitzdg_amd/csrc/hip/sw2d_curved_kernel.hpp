@@ -162,12 +162,33 @@ __global__ __launch_bounds__(256) void sw2d_curved_gauss_kernel(const CurvedPara
     }
 }
 
-// Shallow-water fluxes of one point (reference swhelpers/flux.py:1-22), same operations in the same order.
+// 1/x and sqrt(x) to ~1 ulp without the denormal / infinity fix-up paths of the IEEE sequences (water depth and
+// speeds are well scaled): v_rcp_f64 / v_rsq_f64 + Newton steps, as in the straight-element kernels.
+__device__ __forceinline__ double crcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double csqrt(double x) {
+    x = fmax(x, 1e-290);
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    return g;
+}
+
+// Shallow-water fluxes of one point (reference swhelpers/flux.py:1-22); u = hu * (1/h) formed once.
 struct CurvedFlux {
     double F[4], G[4];
 };
 __device__ __forceinline__ CurvedFlux curved_fluxes(double h, double hu, double hv, double hN, double g) {
-    const double u = hu / h, v = hv / h;
+    const double rh = crcp(h);
+    const double u = hu * rh, v = hv * rh;
     const double pr = 0.5 * g * h * h;
     CurvedFlux o;
     o.F[0] = hu;          o.G[0] = hv;
@@ -180,23 +201,26 @@ __device__ __forceinline__ CurvedFlux curved_fluxes(double h, double hu, double 
 // Momentum sources at a node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx,  S3 = -(f hu - CD |u| v) - g h zy.
 __device__ __forceinline__ void curved_sources(const CurvedParams& p, double h, double hu, double hv, long long rowOff,
                                                unsigned k8, double& S2, double& S3) {
-    const double u = hu / h, v = hv / h;
+    const double rh = crcp(h);
+    const double u = hu * rh, v = hv * rh;
     const double f = p.fcor ? cld_row(p.fcor + rowOff, k8) : p.fconst;
     const double cd = p.cd ? cld_row(p.cd + rowOff, k8) : p.cdconst;
-    const double cdn = cd * sqrt(u * u + v * v);
+    const double cdn = cd * csqrt(u * u + v * v);
     const double zx = p.zx ? cld_row(p.zx + rowOff, k8) : 0.0, zy = p.zy ? cld_row(p.zy + rowOff, k8) : 0.0;
     S2 = (f * hv - cdn * u) - p.g * h * zx;
     S3 = -(f * hu - cdn * v) - p.g * h * zy;
 }
 
 // MODE: CMODE_*; FILTER: the result is Filter * RHS (the drivers filter the whole RHS, sources included);
-// OPSLDS: operator tiles staged in LDS (else read from global memory / L2: images beyond the LDS budget).
-template <int N, int MODE, bool FILTER, bool OPSLDS>
-__global__ __launch_bounds__(256) void sw2d_curved_stage_kernel(const CurvedParams p) {
+// OPSLDS: operator tiles staged in LDS (else read from global memory / L2: images beyond the LDS budget);
+// FB: 16-row blocks per face (1: NGauss <= 16, 2: NGauss <= 32); WAVES: waves per SIMD the register budget is set for.
+template <int N, int MODE, bool FILTER, bool OPSLDS, int FB, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const CurvedParams p) {
     using O = CurvedOps<N>;
     constexpr int Np = O::Np, KV = O::KV, MT = O::MT;
     extern __shared__ double sOps[];
-    const int ncb = p.ncb, fb = p.fb;
+    const int ncb = p.ncb;
+    constexpr int fb = FB;
     const int offDrT = O::offDrT(ncb, fb), offDsT = O::offDsT(ncb, fb), offIT = O::offIT(ncb, fb),
               offMass = FILTER ? O::offMF(ncb, fb) : O::offM(ncb, fb), offF = O::offF(ncb, fb);
     if constexpr (OPSLDS) {
@@ -249,92 +273,96 @@ __global__ __launch_bounds__(256) void sw2d_curved_stage_kernel(const CurvedPara
 #pragma unroll
                 for (int c = 0; c < 4; ++c) cv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], cv[c], 0, 0, 0);
             }
-            double tr[4][4], ts[4][4];
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
+            for (int reg = 0; reg < 4; ++reg) { // 4 cubature points of this lane = contraction step reg of DrT / DsT
                 const int row = 16 * rb + static_cast<int>(q) + 4 * reg;
                 const long long ro = static_cast<long long>(row) * ld;
                 const double wrx = cld_row(p.cubG + ro, k8), wry = cld_row(p.cubG + cplane + ro, k8),
                              wsx = cld_row(p.cubG + 2 * cplane + ro, k8), wsy = cld_row(p.cubG + 3 * cplane + ro, k8);
                 const bool valid = row < p.ncub;
                 const CurvedFlux fl = curved_fluxes(valid ? cv[0][reg] : 1.0, cv[1][reg], cv[2][reg], cv[3][reg], g);
+                double tr[4], ts[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    tr[c][reg] = wrx * fl.F[c] + wry * fl.G[c];
-                    ts[c][reg] = wsx * fl.F[c] + wsy * fl.G[c];
+                    tr[c] = wrx * fl.F[c] + wry * fl.G[c];
+                    ts[c] = wsx * fl.F[c] + wsy * fl.G[c];
                 }
-            }
 #pragma unroll
-            for (int r = 0; r < MT; ++r)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
+                for (int r = 0; r < MT; ++r) {
                     const double aDr = A(offDrT + (r * ncb + rb) * 4 + reg), aDs = A(offDsT + (r * ncb + rb) * 4 + reg);
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDr, tr[c][reg], acc[c][r], 0, 0, 0);
-                        acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDs, ts[c][reg], acc[c][r], 0, 0, 0);
+                        acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDr, tr[c], acc[c][r], 0, 0, 0);
+                        acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDs, ts[c], acc[c][r], 0, 0, 0);
                     }
-                }
-        }
-
-        // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face
-        for (int f = 0; f < 3; ++f) {
-            double lam = 0.0;
-            for (int pass = 0; pass < 2; ++pass) { // pass 0: the face's maximum speed; pass 1: fluxes with it
-                for (int b = 0; b < fb; ++b) {
-                    const int gb = f * fb + b;
-                    double sflux[4][4];
-#pragma unroll
-                    for (int reg = 0; reg < 4; ++reg) {
-                        const int local = 16 * b + static_cast<int>(q) + 4 * reg, gr = 16 * gb + static_cast<int>(q) + 4 * reg;
-                        const bool valid = local < p.ng;
-                        const long long go = static_cast<long long>(gr) * ld;
-                        const int idP = cld_row(p.gmapP + go, k4);
-                        const unsigned oP = static_cast<unsigned>(idP < 0 ? -(idP + 1) : idP) * 8u;
-                        const unsigned oM = p.gmapM ? static_cast<unsigned>(cld_row(p.gmapM + go, k4)) * 8u
-                                                    : static_cast<unsigned>(go) * 8u + k8;
-                        double hM = cld_row(p.gq, oM), huM = cld_row(p.gq + gplane, oM), hvM = cld_row(p.gq + 2 * gplane, oM),
-                               hNM = cld_row(p.gq + 3 * gplane, oM);
-                        double hP = cld_row(p.gq, oP), huP = cld_row(p.gq + gplane, oP), hvP = cld_row(p.gq + 2 * gplane, oP),
-                               hNP = cld_row(p.gq + 3 * gplane, oP);
-                        if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
-                        const double uM = huM / hM, uP = huP / hP, vM = hvM / hM, vP = hvP / hP; // before the wall condition (rhs.py:81-85)
-                        if (pass == 0) {
-                            const double spdM = sqrt(uM * uM + vM * vM) + sqrt(g * hM);
-                            const double spdP = sqrt(uP * uP + vP * vP) + sqrt(g * hP);
-                            lam = valid ? fmax(lam, fmax(spdM, spdP)) : lam;
-                        } else {
-                            const double nx = cld_row(p.gaussG + go, k8), ny = cld_row(p.gaussG + gplane + go, k8),
-                                         W = cld_row(p.gaussG + 2 * gplane + go, k8);
-                            if (idP < 0) { // reflective wall (rhs.py:87-88)
-                                const double un = huM * nx + hvM * ny;
-                                huP = huM - 2 * nx * un;
-                                hvP = hvM - 2 * ny * un;
-                            }
-                            const CurvedFlux fM = curved_fluxes(hM, huM, hvM, hNM, g), fP = curved_fluxes(hP, huP, hvP, hNP, g);
-                            const double dq[4] = {hM - hP, huM - huP, hvM - hvP, hNM - hNP};
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                sflux[c][reg] = W * (0.5 * ((fM.F[c] + fP.F[c]) * nx + (fM.G[c] + fP.G[c]) * ny + lam * dq[c]));
-                        }
-                    }
-                    if (pass == 1) {
-#pragma unroll
-                        for (int r = 0; r < MT; ++r)
-#pragma unroll
-                            for (int reg = 0; reg < 4; ++reg) {
-                                const double a = A(offIT + (r * 3 * fb + gb) * 4 + reg);
-#pragma unroll
-                                for (int c = 0; c < 4; ++c)
-                                    acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sflux[c][reg], acc[c][r], 0, 0, 0);
-                            }
-                    }
-                }
-                if (pass == 0) { // the face's Gauss points sit in the 4 lanes q of this element
-                    lam = fmax(lam, __shfl_xor(lam, 16));
-                    lam = fmax(lam, __shfl_xor(lam, 32));
                 }
             }
+        }
+
+        // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face. One pass: the
+        //      weighted central flux and jump of every point stay in registers until the face's speed is known.
+#pragma unroll 1
+        for (int f = 0; f < 3; ++f) {
+            double lam = 0.0;
+            double ef[FB][4][4], dj[FB][4][4];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int gb = f * FB + b;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int local = 16 * b + static_cast<int>(q) + 4 * reg, gr = 16 * gb + static_cast<int>(q) + 4 * reg;
+                    const bool valid = local < p.ng;
+                    const long long go = static_cast<long long>(gr) * ld;
+                    const int idP = cld_row(p.gmapP + go, k4);
+                    const unsigned oP = static_cast<unsigned>(idP < 0 ? -(idP + 1) : idP) * 8u;
+                    const unsigned oM = p.gmapM ? static_cast<unsigned>(cld_row(p.gmapM + go, k4)) * 8u
+                                                : static_cast<unsigned>(go) * 8u + k8;
+                    double hM = cld_row(p.gq, oM), huM = cld_row(p.gq + gplane, oM), hvM = cld_row(p.gq + 2 * gplane, oM),
+                           hNM = cld_row(p.gq + 3 * gplane, oM);
+                    double hP = cld_row(p.gq, oP), huP = cld_row(p.gq + gplane, oP), hvP = cld_row(p.gq + 2 * gplane, oP),
+                           hNP = cld_row(p.gq + 3 * gplane, oP);
+                    const double nx = cld_row(p.gaussG + go, k8), ny = cld_row(p.gaussG + gplane + go, k8),
+                                 hW = 0.5 * cld_row(p.gaussG + 2 * gplane + go, k8); // zero on padding rows
+                    if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
+                    const double rM = crcp(hM), rP = crcp(hP);
+                    // the wave speeds use the exterior velocity BEFORE the wall condition (rhs.py:81-85, :93-94)
+                    const double uM = huM * rM, vM = hvM * rM, uP0 = huP * rP, vP0 = hvP * rP;
+                    const double spdM = csqrt(uM * uM + vM * vM) + csqrt(g * hM);
+                    const double spdP = csqrt(uP0 * uP0 + vP0 * vP0) + csqrt(g * hP);
+                    lam = valid ? fmax(lam, fmax(spdM, spdP)) : lam;
+                    if (idP < 0) { // reflective wall (rhs.py:87-88)
+                        const double un = huM * nx + hvM * ny;
+                        huP = huM - 2 * nx * un;
+                        hvP = hvM - 2 * ny * un;
+                    }
+                    const double uP = huP * rP, vP = hvP * rP;
+                    const double prM = 0.5 * g * hM * hM, prP = 0.5 * g * hP * hP;
+                    const double F[4] = {huM + huP, (huM * uM + prM) + (huP * uP + prP), hvM * uM + hvP * uP, hNM * uM + hNP * uP};
+                    const double G[4] = {hvM + hvP, huM * vM + huP * vP, (hvM * vM + prM) + (hvP * vP + prP), hNM * vM + hNP * vP};
+                    const double dq[4] = {hM - hP, huM - huP, hvM - hvP, hNM - hNP};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ef[b][reg][c] = hW * (F[c] * nx + G[c] * ny);
+                        dj[b][reg][c] = hW * dq[c];
+                    }
+                }
+            }
+            lam = fmax(lam, __shfl_xor(lam, 16)); // the face's Gauss points sit in the 4 lanes q of this element
+            lam = fmax(lam, __shfl_xor(lam, 32));
+#pragma unroll
+            for (int b = 0; b < FB; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    double sf[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sf[c] = fma(lam, dj[b][reg][c], ef[b][reg][c]);
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        const double a = A(offIT + (r * 3 * FB + f * FB + b) * 4 + reg);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sf[c], acc[c][r], 0, 0, 0);
+                    }
+                }
         }
 
         // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
@@ -396,70 +424,77 @@ __global__ __launch_bounds__(256) void sw2d_curved_stage_kernel(const CurvedPara
 }
 
 // ---- elements of curvedEls: RHS_c = U^-1 U^-T MM_c with the element's own Cholesky factor (rhs.py:157-162), then
-// sources, filter and update as above. One lane per element; columns of the side buffers are contiguous.
+// sources, filter and update as above. One lane per (element, field); columns of the side buffers are contiguous in the
+// element slot, so a wave's loads of one matrix entry are coalesced, and a whole row of U is requested at once
+// (2 Np round trips per solve instead of Np^2). cholSide holds 1 / U_ii on the diagonal.
 template <int N, int MODE, bool FILTER>
 __global__ __launch_bounds__(64) void sw2d_curved_fixup_kernel(const CurvedParams p) {
     constexpr int Np = (N + 1) * (N + 2) / 2;
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
     if (slot >= p.numCurved) return;
     const unsigned k = static_cast<unsigned>(p.curvedEls[slot]), k8 = k * 8u;
     const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, sld = p.sideLd;
     const double* __restrict__ U = p.cholSide + slot; // U[i][j] at U[(i*Np + j) * sld]
-    double h[Np], hu[Np], hv[Np];
+    double x[Np];
+#pragma unroll
+    for (int m = 0; m < Np; ++m) x[m] = p.mmSide[(static_cast<long long>(c) * Np + m) * sld + slot];
+    // U^T y = b, column-oriented: y_j = b_j / U_jj, then b_i -= U_ji y_j for i > j (row j of U in one batch of loads)
 #pragma unroll 1
-    for (int m = 0; m < Np; ++m) {
-        h[m] = cld_row(p.qin + m * ld, k8);
-        hu[m] = cld_row(p.qin + plane + m * ld, k8);
-        hv[m] = cld_row(p.qin + 2 * plane + m * ld, k8);
+    for (int jj = 0; jj < Np; ++jj) {
+        double row[Np];
+#pragma unroll
+        for (int i = 0; i < Np; ++i) row[i] = U[(static_cast<long long>(jj) * Np + i) * sld];
+        double yj = 0.0;
+#pragma unroll
+        for (int i = 0; i < Np; ++i) yj = i == jj ? x[i] * row[i] : yj;
+#pragma unroll
+        for (int i = 0; i < Np; ++i) x[i] = i == jj ? yj : (i > jj ? fma(-row[i], yj, x[i]) : x[i]);
     }
-    for (int c = 0; c < 4; ++c) {
-        double x[Np], r[Np];
+    // U x = y, row-oriented from the last row: x_i = (y_i - sum_{j > i} U_ij x_j) / U_ii
 #pragma unroll 1
-        for (int m = 0; m < Np; ++m) x[m] = p.mmSide[(static_cast<long long>(c) * Np + m) * sld + slot];
-        // U^T y = b (forward), then U x = y (backward)
-#pragma unroll 1
-        for (int i = 0; i < Np; ++i) {
-            double s = x[i];
-            for (int jj = 0; jj < i; ++jj) s -= U[(static_cast<long long>(jj) * Np + i) * sld] * x[jj];
-            x[i] = s / U[(static_cast<long long>(i) * Np + i) * sld];
+    for (int i = Np - 1; i >= 0; --i) {
+        double row[Np];
+#pragma unroll
+        for (int jj = 0; jj < Np; ++jj) row[jj] = U[(static_cast<long long>(i) * Np + jj) * sld];
+        double sacc = 0.0, yi = 0.0, rd = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < Np; ++jj) {
+            sacc = jj > i ? fma(row[jj], x[jj], sacc) : sacc;
+            yi = jj == i ? x[jj] : yi;
+            rd = jj == i ? row[jj] : rd;
         }
-#pragma unroll 1
-        for (int i = Np - 1; i >= 0; --i) {
-            double s = x[i];
-            for (int jj = i + 1; jj < Np; ++jj) s -= U[(static_cast<long long>(i) * Np + jj) * sld] * x[jj];
-            x[i] = s / U[(static_cast<long long>(i) * Np + i) * sld];
-        }
-        if (c == 1 || c == 2) {
-#pragma unroll 1
-            for (int m = 0; m < Np; ++m) {
-                double S2, S3;
-                curved_sources(p, h[m], hu[m], hv[m], m * ld, k8, S2, S3);
-                x[m] += c == 1 ? S2 : S3;
-            }
-        }
-        if constexpr (FILTER) {
-#pragma unroll 1
-            for (int i = 0; i < Np; ++i) {
-                double s = 0.0;
-                for (int m = 0; m < Np; ++m) s += p.filt[i * Np + m] * x[m];
-                r[i] = s;
-            }
-        } else {
-#pragma unroll 1
-            for (int i = 0; i < Np; ++i) r[i] = x[i];
-        }
-#pragma unroll 1
+        const double xi = (yi - sacc) * rd;
+#pragma unroll
+        for (int jj = 0; jj < Np; ++jj) x[jj] = jj == i ? xi : x[jj];
+    }
+    if (c == 1 || c == 2) {
+#pragma unroll
         for (int m = 0; m < Np; ++m) {
-            const long long off = c * plane + m * ld;
-            if constexpr (MODE == CMODE_RHS) {
-                cst_row(p.rhs + off, k8, r[m]);
-            } else if constexpr (MODE == CMODE_LSERK) {
-                const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * r[m];
-                cst_row(p.res + off, k8, n1);
-                cst_row(p.qout + off, k8, cld_row(p.qin + off, k8) + p.cb * n1);
-            } else {
-                cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * cld_row(p.qin + off, k8) + p.cc * r[m]);
-            }
+            double S2, S3;
+            curved_sources(p, cld_row(p.qin + m * ld, k8), cld_row(p.qin + plane + m * ld, k8),
+                           cld_row(p.qin + 2 * plane + m * ld, k8), m * ld, k8, S2, S3);
+            x[m] += c == 1 ? S2 : S3;
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < Np; ++i) {
+        double r = 0.0;
+        if constexpr (FILTER) {
+#pragma unroll
+            for (int m = 0; m < Np; ++m) r = fma(p.filt[i * Np + m], x[m], r);
+        } else {
+#pragma unroll
+            for (int m = 0; m < Np; ++m) r = m == i ? x[m] : r;
+        }
+        const long long off = c * plane + i * ld;
+        if constexpr (MODE == CMODE_RHS) {
+            cst_row(p.rhs + off, k8, r);
+        } else if constexpr (MODE == CMODE_LSERK) {
+            const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * r;
+            cst_row(p.res + off, k8, n1);
+            cst_row(p.qout + off, k8, cld_row(p.qin + off, k8) + p.cb * n1);
+        } else {
+            cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * cld_row(p.qin + off, k8) + p.cc * r);
         }
     }
 }

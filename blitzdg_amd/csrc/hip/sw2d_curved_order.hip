@@ -1,6 +1,7 @@
 // Instantiates the curved / over-integrated sw2d kernels for one polynomial order (-DBDG_ORDER=N).
 #include "sw2d_curved_kernel.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 #ifndef BDG_ORDER
 #error "compile with -DBDG_ORDER=<polynomial order>"
@@ -14,6 +15,9 @@ using O = CurvedOps<kN>;
 // Dynamic LDS a workgroup of the stage kernel may claim for the operator image; beyond it the tiles are read
 // from global memory (they stay in L1 / L2: every wave reads the same image).
 constexpr int kLdsBudgetBytes = 150 * 1024;
+// measured (profiles/r02_curved_*): N=4 0.74 ms at 2 waves (118 spilled VGPRs) against 0.84 ms at 1; N=6 1.82 against
+// 1.42 ms; N=8 3.11 against 3.34 ms
+constexpr int kDefaultWaves = (BDG_ORDER <= 4 || BDG_ORDER >= 8) ? 2 : 1;
 
 int opsTiles(int ncb, int fb) { return O::tiles(ncb, fb); }
 int stageTiles(int ncb, int fb) { return O::offGI(ncb, fb); }
@@ -34,12 +38,32 @@ hipError_t gauss(const CurvedParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int MODE, bool FILTER, int FB, int WAVES>
+hipError_t launchStageFb(const CurvedParams& p, hipStream_t stream);
+
+// Register budget: BDG_SW2D_CURVED_WAVES = 1 | 2 waves per SIMD (A/B switch; default below).
+int curvedWaves() {
+    static const int w = [] {
+        const char* e = std::getenv("BDG_SW2D_CURVED_WAVES");
+        return (e && e[0] == '2') ? 2 : ((e && e[0] == '1') ? 1 : kDefaultWaves);
+    }();
+    return w;
+}
+
 template <int MODE, bool FILTER>
 hipError_t launchStage(const CurvedParams& p, hipStream_t stream) {
+    const bool two = curvedWaves() == 2;
+    if (p.fb == 1) return two ? launchStageFb<MODE, FILTER, 1, 2>(p, stream) : launchStageFb<MODE, FILTER, 1, 1>(p, stream);
+    if (p.fb == 2) return two ? launchStageFb<MODE, FILTER, 2, 2>(p, stream) : launchStageFb<MODE, FILTER, 2, 1>(p, stream);
+    return hipErrorInvalidValue; // more than 32 Gauss points per face: refused at creation
+}
+
+template <int MODE, bool FILTER, int FB, int WAVES>
+hipError_t launchStageFb(const CurvedParams& p, hipStream_t stream) {
     if (p.K < 1) return hipSuccess;
     const size_t lds = static_cast<size_t>(O::offGI(p.ncb, p.fb)) * 64 * sizeof(double);
     if (lds <= static_cast<size_t>(kLdsBudgetBytes)) {
-        auto kern = sw2d_curved_stage_kernel<kN, MODE, FILTER, true>;
+        auto kern = sw2d_curved_stage_kernel<kN, MODE, FILTER, true, FB, WAVES>;
         if (lds > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -48,7 +72,7 @@ hipError_t launchStage(const CurvedParams& p, hipStream_t stream) {
         const int wgPerCu = std::max(1, static_cast<int>(160 * 1024 / std::max<size_t>(lds, 1)));
         hipLaunchKernelGGL(kern, dim3(gridFor(p.K, std::min(wgPerCu, 2))), dim3(256), lds, stream, p);
     } else {
-        hipLaunchKernelGGL((sw2d_curved_stage_kernel<kN, MODE, FILTER, false>), dim3(gridFor(p.K, 2)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((sw2d_curved_stage_kernel<kN, MODE, FILTER, false, FB, WAVES>), dim3(gridFor(p.K, 2)), dim3(256), 0, stream, p);
     }
     return hipGetLastError();
 }
@@ -65,7 +89,7 @@ hipError_t stage(int mode, bool filter, const CurvedParams& p, hipStream_t strea
 template <int MODE, bool FILTER>
 hipError_t launchFixup(const CurvedParams& p, hipStream_t stream) {
     if (p.numCurved < 1) return hipSuccess;
-    hipLaunchKernelGGL((sw2d_curved_fixup_kernel<kN, MODE, FILTER>), dim3((p.numCurved + 63) / 64), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL((sw2d_curved_fixup_kernel<kN, MODE, FILTER>), dim3((p.numCurved + 63) / 64, 4), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 

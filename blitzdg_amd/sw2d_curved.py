@@ -51,7 +51,8 @@ class Sw2dCurvedSolver:
         d = C.Sw2dCurvedDesc()
         d.order, d.num_elements, d.num_cub, d.num_gauss = order, K, Ncub, NG
         d.V = f64(ctx.V, (Np, Np), "ctx.V")
-        d.Filter = f64(filt, (Np, Np), "ctx.filter") if filt is not None and np.size(filt) == Np * Np else None
+        # a provisioner whose buildFilter was never called hands out an all-zero (or empty) table: no filter
+        d.Filter = f64(filt, (Np, Np), "ctx.filter") if filt is not None and np.size(filt) == Np * Np and np.any(filt) else None
         d.J = f64(J, (Np, K), "J")
         d.cubV = f64(cubV, (Ncub, Np), "cub_ctx.V")
         d.cubDr, d.cubDs = f64(cub_ctx.Dr, (Ncub, Np), "cub_ctx.Dr"), f64(cub_ctx.Ds, (Ncub, Np), "cub_ctx.Ds")
