@@ -433,6 +433,9 @@ struct bdg_sw2d {
         } else if (affine && variant == 5) {
             p.opsAffine = filter ? opsMfmaFiltered.p : opsMfma.p;
             hipCheck(kt->stageMfma(mode, p, st), what);
+        } else if (affine && variant == 7) {
+            p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
+            hipCheck(kt->stageMfma3(mode, p, st), what);
         } else if (affine && variant == 6) {
             p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
             hipCheck(kt->stageMfma2(mode, p, st), what);
@@ -963,10 +966,12 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     // Measured on MI355X: the fully unrolled vector kernel wins up to N=4; from
     // N=5 on its basic block outgrows the register files and the matrix-core kernel is fastest
     // (N=5, 640 k elements: 0.454 ms unrolled, 0.405 ms matrix cores).
-    s->affineVariant = s->N <= 4 ? 0 : 6;
+    // From N = 5 the default is the state-once matrix-core schedule (variant 7; measured against variant 6 at
+    // 640 k / 500 k / 250 k / 250 k elements: N=5 0.36 vs 0.42 ms, N=6 0.33 vs 0.40, N=7 0.24 vs 0.28, N=8 0.30 vs 0.39).
+    s->affineVariant = s->N <= 4 ? 0 : 7;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 6) {
+        if (v >= 0 && v <= 7) {
             s->affineVariant = v;
             s->variantForced = true;
         }

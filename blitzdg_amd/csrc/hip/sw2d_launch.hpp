@@ -7,6 +7,7 @@
 #include "sw2d_tracer_kernel.hpp"
 #include "sw2d_vb_kernel.hpp"
 #include "sw2d_mfma_kernel.hpp"
+#include "sw2d_mfma3_kernel.hpp"
 #include "sw2d_kernels.hpp"
 
 namespace bdg_dev {
@@ -26,6 +27,9 @@ struct KernelTable {
     hipError_t (*stageMfma2Halo)(const StageParams& p, hipStream_t stream); // the same on the face-by-face kernel (N >= 5)
     int mfma2OpsDoubles, mfma2KF; // face-by-face schedule (lift tiles padded per face)
     hipError_t (*stageMfma2)(int mode, const StageParams& p, hipStream_t stream);
+    // state-once schedule, one wave per SIMD with software-pipelined loads (same MfmaOps2 image; three fields, no
+    // sources, no halo staging): sw2d_mfma3_kernel.hpp
+    hipError_t (*stageMfma3)(int mode, const StageParams& p, hipStream_t stream);
     // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the
     // tracer-equation pass (plain MfmaOps2 image); tracer = 2: variant B (image as for the sources)
     hipError_t (*stageMfma2Src)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);

@@ -1,0 +1,320 @@
+// sw2d_mfma3_kernel.hpp -- third schedule of the matrix-core stage kernel (variant A, three fields, straight-sided
+// elements): every element's state is read from HBM ONCE per stage.
+//
+// The two-waves-per-SIMD schedule (sw2d_stage_mfma2_kernel) touches the state three times -- volume chunks, interior
+// face traces, stage update -- and with 256 waves per XCD each holding a 17 KB tile (N=8) the second and third touch
+// miss the 4 MB L2: profiles/r01_n8_pmc_summary.json shows 1.43 GB of reads per launch against 0.59 GB compulsory.
+// Here a wave (one per SIMD, 512 registers) keeps its tile of 16 elements in registers in MFMA operand layout
+// (node m = 4 t + q, which is both the B-operand layout of the volume term and the C/D layout of the result, so the
+// stage update needs no second load), parks a copy in a wave-private LDS tile from which the interior face traces
+// are read back (a face node lives in another lane's registers), and hides memory latency by software pipelining
+// instead of by a second wave: the next tile's state and gather indices, this tile's neighbour traces and residual
+// are all requested well before their first use, in batches pinned with scheduling barriers.
+//   per tile:  LDS copy  ->  volume k-step t  [pointwise work of one face node; next tile: state row t, traces of a
+//              finished face]  ->  [residual rows, next tile: geometry]  ->  faces (matrix instructions only)
+//              ->  update (own state back from the LDS copy) + stores
+// A register that held a state row (a face's neighbour traces) is free once that k-step's (face's) operands exist, so
+// the next tile's copy of it is requested right there and nothing of a tile is waited for at its start.
+// Same operator image (MfmaOps2) and the same arithmetic as sw2d_stage_mfma2_kernel<N, MODE, 0>.
+#pragma once
+#include "sw2d_mfma_kernel.hpp"
+
+namespace bdg_dev {
+
+// Row accesses go through buffer instructions: a wave-uniform descriptor per plane, ONE per-lane byte offset per tile
+// ((q ld + k) 8: lane (q, j) always touches rows 4 t + q of its element k) and the row group 4 t as a scalar offset.
+// No per-load 64-bit address lives in vector registers (72 row loads in flight would need 144 of them), and rows
+// beyond the plane (the padding nodes m >= Np of the last k-step) are bounds-checked away by the hardware.
+typedef unsigned int bdg_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double bld_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ int bld_i32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bst_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bdg_u32x2, v), r, voff, soff, 0);
+}
+
+template <int N>
+struct Mfma3Lds {
+    using O = MfmaOps2<N>;
+    static constexpr int TILE_DOUBLES = 3 * Elem<N>::Np * 16;          // one wave's state tile [field][node][element]
+    static constexpr int DOUBLES = O::DOUBLES + 4 * TILE_DOUBLES;      // operator image + four waves' tiles
+};
+
+template <int N, int MODE>
+__global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StageParams p) {
+    using E = Elem<N>;
+    using O = MfmaOps2<N>;
+    constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
+
+    extern __shared__ double sOps[];
+    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    __syncthreads();
+    // this wave's state tile; indexed through sOps so that the accesses stay LDS instructions (a generic pointer
+    // would turn them into flat_load / flat_store, which also wait for every outstanding global load)
+    const int sBase = O::DOUBLES + static_cast<int>(threadIdx.x >> 6) * Mfma3Lds<N>::TILE_DOUBLES + static_cast<int>(threadIdx.x & 15u);
+
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
+    const unsigned blk = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
+    const unsigned wave = blk * 4u + (threadIdx.x >> 6), nwaves = nwg * 4u;
+    const unsigned ntiles = (static_cast<unsigned>(p.kend - p.kbegin) + 15u) / 16u;
+    const unsigned perWave = (ntiles + nwaves - 1u) / nwaves;
+    const unsigned tileEnd = min(ntiles, (wave + 1u) * perWave);
+    unsigned tile = wave * perWave;
+    if (tile >= tileEnd) return;
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
+    const double g = p.g, halfg = 0.5 * p.g;
+    const unsigned kLast = static_cast<unsigned>(p.kend) - 1u;
+    const unsigned planeBytes = static_cast<unsigned>(plane * 8), ld8 = static_cast<unsigned>(ld) * 8u, ld4 = static_cast<unsigned>(ld) * 4u;
+    __amdgpu_buffer_rsrc_t rq[3], rold[3], rout[3], rres[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        rq[c] = plane_rsrc(p.qin + c * plane, planeBytes);
+        rold[c] = plane_rsrc((MODE == MODE_LSERK ? p.res : (MODE == MODE_COMBINE ? p.qbase : p.qin)) + c * plane, planeBytes);
+        rout[c] = plane_rsrc((MODE == MODE_RHS ? p.rhs : p.qout) + c * plane, planeBytes);
+        rres[c] = plane_rsrc((MODE == MODE_LSERK ? p.res : p.qin) + c * plane, planeBytes);
+    }
+    const __amdgpu_buffer_rsrc_t rgeo = plane_rsrc(p.ageo, 13u * ld8), ridx = plane_rsrc(p.vmapP, 3u * Nfp * ld4);
+
+    // element of this lane in tile `tl` (padding lanes recompute the last element and store nothing)
+    auto elementOf = [&](unsigned tl, bool& live) {
+        const unsigned kTrue = static_cast<unsigned>(p.kbegin) + tl * 16u + j;
+        live = kTrue <= kLast;
+        return live ? kTrue : kLast;
+    };
+    // Row 4 t + q of element kk sits at byte offset (q ld + kk) 8 + t (4 ld 8). Loaded values are used as they come:
+    // any fix-up of padding rows happens where a value is consumed, so that a load never has to be waited for early.
+    auto loadStateRow = [&](unsigned kk, int t, double (&qs)[3][KV]) {
+        const unsigned v8 = (q * static_cast<unsigned>(ld) + kk) * 8u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) qs[c][t] = bld_f64(rq[c], v8, static_cast<unsigned>(4 * t) * ld8); // 0 beyond the plane
+    };
+    auto loadIndices = [&](unsigned kk, int (&ix)[3][KF]) {
+        const unsigned v4 = (q * static_cast<unsigned>(ld) + kk) * 4u;
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) ix[f][tf] = bld_i32(ridx, v4, static_cast<unsigned>(f * Nfp + 4 * tf) * ld4);
+    };
+    auto loadGeometry = [&](unsigned kk, double (&gg)[13]) {
+#pragma unroll
+        for (int i = 0; i < 13; ++i) gg[i] = bld_f64(rgeo, kk * 8u, static_cast<unsigned>(i) * ld8);
+    };
+    // neighbour traces of face f (face node n = 4 tf + q); lanes beyond the face read node 0 of element 0 and ignore it
+    auto loadTraces = [&](int f, const int (&ix)[3][KF], double (&a)[3][KF], double (&b)[3][KF], double (&c3)[3][KF]) {
+#pragma unroll
+        for (int tf = 0; tf < KF; ++tf) {
+            const int n = 4 * tf + static_cast<int>(q);
+            const int id = n < Nfp ? ix[f][tf] : 0;
+            const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
+            a[f][tf] = bld_f64(rq[0], o8, 0u);
+            b[f][tf] = bld_f64(rq[1], o8, 0u);
+            c3[f][tf] = bld_f64(rq[2], o8, 0u);
+        }
+    };
+
+    bool live;
+    unsigned k = elementOf(tile, live);
+    double qB[3][KV], geo[13], hP[3][KF], huP[3][KF], hvP[3][KF];
+    int fidx[3][KF];
+    loadIndices(k, fidx);
+#pragma unroll
+    for (int t = 0; t < KV; ++t) loadStateRow(k, t, qB);
+    loadGeometry(k, geo);
+#pragma unroll
+    for (int f = 0; f < 3; ++f) loadTraces(f, fidx, hP, huP, hvP);
+
+#pragma unroll 1
+    for (;;) {
+        const unsigned v8 = (q * static_cast<unsigned>(ld) + k) * 8u;
+        const bool more = tile + 1u < tileEnd;
+        bool liveN = false;
+        const unsigned kN = more ? elementOf(tile + 1u, liveN) : k;
+        // next tile, requested piece by piece below as this tile's registers fall free
+        double qN[3][KV], geoN[13], hPN[3][KF], huPN[3][KF], hvPN[3][KF];
+        int fidxN[3][KF];
+
+        // ---- own state into the wave's LDS tile (face traces and the update read it back from there)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const int m = 4 * t + static_cast<int>(q);
+                if (m < Np) sOps[sBase + (c * Np + m) * 16] = qB[c][t];
+            }
+        __builtin_amdgcn_wave_barrier(); // other lanes of this wave read these values back (DS operations of a wave execute in order)
+
+        mfma_acc_t acc[3][MT];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) acc[c][r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+
+        const double rx = geo[0], sx = geo[1], ry = geo[2], sy = geo[3];
+        // volume term, software pipelined by hand: the six operands of k-step t + 1 are formed (vector ALU) in the same
+        // scheduling region as the 6 MT matrix instructions of k-step t, so the two pipes overlap within one wave; the
+        // state rows of k-step t are dead by then and the same rows of the NEXT tile are requested in their place
+        auto volumeOperands = [&](int t, double (&ab)[6]) {
+            const int m = 4 * t + static_cast<int>(q);
+            const bool pad = m >= Np;
+            const double h = pad ? 1.0 : qB[0][t], hu = qB[1][t], hv = qB[2][t];
+            const double r = fast_rcp(h);
+            const double u = hu * r, v = hv * r;
+            const double pr = halfg * h * h;
+            const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
+            const double w = pad ? 0.0 : -1.0; // zero the padded rows of the operand
+            ab[0] = w * (rx * hu + ry * hv); ab[1] = w * (sx * hu + sy * hv);
+            ab[2] = w * (rx * F2 + ry * G2); ab[3] = w * (sx * F2 + sy * G2);
+            ab[4] = w * (rx * G2 + ry * G3); ab[5] = w * (sx * G2 + sy * G3);
+        };
+        // Pointwise work of the surface term (face node n = 4 tf + q of face f; '-' traces from the LDS tile, '+' traces
+        // prefetched during the previous tile), one face node per lane at a time: it is spread over the volume k-steps,
+        // whose matrix instructions leave the vector ALU mostly idle, so that the faces' own matrix instructions later
+        // run back to back. A face's operands s_c = Fscale/2 (e_c - lam d_c) are final once its last node is in.
+        double sF[3][3][KF];
+        double eF[3][KF], dF[3][KF], lamF = 0.0;
+        auto faceNode = [&](int f, int tf) {
+            const double nxf = geo[4 + f], nyf = geo[7 + f];
+            const int n = 4 * tf + static_cast<int>(q);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) eF[c][tf] = dF[c][tf] = 0.0;
+            if (n < Nfp) {
+                const int m = fmask_rt<N>(f, n);
+                const double hM = sOps[sBase + m * 16], huM = sOps[sBase + (Np + m) * 16], hvM = sOps[sBase + (2 * Np + m) * 16];
+                const double hq = hP[f][tf];
+                double huq = huP[f][tf], hvq = hvP[f][tf];
+                if (fidx[f][tf] < 0) { // reflective wall: no normal flow
+                    const double un = huM * nxf + hvM * nyf;
+                    huq = huM - 2 * nxf * un;
+                    hvq = hvM - 2 * nyf * un;
+                }
+                const double rM = fast_rcp(hM), rP = fast_rcp(hq);
+                const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
+                const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                lamF = fmax(lamF, fmax(spdM, spdP));
+                const double prM = halfg * hM * hM, prP = halfg * hq * hq;
+                const double F2M = huM * uM + prM, G2M = huM * vM, G3M = hvM * vM + prM;
+                const double F2P = huq * uP + prP, G2P = huq * vP, G3P = hvq * vP + prP;
+                dF[0][tf] = hM - hq; dF[1][tf] = huM - huq; dF[2][tf] = hvM - hvq;
+                eF[0][tf] = dF[1][tf] * nxf + dF[2][tf] * nyf;
+                eF[1][tf] = (F2M - F2P) * nxf + (G2M - G2P) * nyf;
+                eF[2][tf] = (G2M - G2P) * nxf + (G3M - G3P) * nyf;
+            }
+            if (tf == KF - 1) { // the face is complete: its speed (the face's nodes sit in the 4 lanes q of this element)
+                double lam = fmax(lamF, __shfl_xor(lamF, 16));
+                lam = fmax(lam, __shfl_xor(lam, 32));
+                const double hfs = 0.5 * geo[10 + f];
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int t2 = 0; t2 < KF; ++t2) sF[f][c][t2] = hfs * (eF[c][t2] - lam * dF[c][t2]);
+                lamF = 0.0;
+                loadTraces(f, fidxN, hPN, huPN, hvPN); // this face's '+' traces are dead: request the next tile's
+            }
+        };
+        constexpr int FACE_ITEMS = 3 * KF, PER_STEP = (FACE_ITEMS + KV - 1) / KV;
+
+        double abCur[6], abNext[6];
+        volumeOperands(0, abCur);
+        loadIndices(kN, fidxN);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < KV; ++t) {
+            if (t + 1 < KV) volumeOperands(t + 1, abNext);
+            loadStateRow(kN, t, qN);
+#pragma unroll
+            for (int it = t * PER_STEP; it < (t + 1) * PER_STEP; ++it)
+                if (it < FACE_ITEMS) faceNode(it / KF, it % KF);
+#pragma unroll
+            for (int r2 = 0; r2 < MT; ++r2) {
+                const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
+                const double Ads = sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane];
+                acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[0], acc[0][r2], 0, 0, 0);
+                acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[2], acc[1][r2], 0, 0, 0);
+                acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[4], acc[2][r2], 0, 0, 0);
+                acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[1], acc[0][r2], 0, 0, 0);
+                acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[3], acc[1][r2], 0, 0, 0);
+                acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[5], acc[2][r2], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) abCur[i] = abNext[i];
+        }
+
+        // ---- residual (LSERK) / base state (COMBINE) rows of this tile, consumed by the update after the faces
+        double oldv[3][KV];
+        if constexpr (MODE != MODE_RHS) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int t = 0; t < KV; ++t) oldv[c][t] = bld_f64(rold[c], v8, static_cast<unsigned>(4 * t) * ld8);
+        }
+        loadGeometry(kN, geoN);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- surface term: matrix instructions only (operands formed above)
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf)
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    const double Al = sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane];
+                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][0][tf], acc[0][r], 0, 0, 0);
+                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][1][tf], acc[1][r], 0, 0, 0);
+                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][2][tf], acc[2][r], 0, 0, 0);
+                }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- stage update / output: node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3); stores of the
+        //      padding rows fall outside the plane and are dropped by the bounds check, padding lanes store nothing
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int t = 0; t < KV; ++t) {
+                    const int m = 4 * t + static_cast<int>(q);
+                    const unsigned soff = static_cast<unsigned>(4 * t) * ld8;
+                    const double R = acc[c][t >> 2][t & 3];
+                    const double own = m < Np ? sOps[sBase + (c * Np + m) * 16] : 0.0;
+                    if constexpr (MODE == MODE_RHS) {
+                        bst_f64(rout[c], v8, soff, R);
+                    } else if constexpr (MODE == MODE_LSERK) {
+                        const double n1 = p.ca * oldv[c][t] + p.cc * R;
+                        bst_f64(rres[c], v8, soff, n1);
+                        bst_f64(rout[c], v8, soff, own + p.cb * n1);
+                    } else {
+                        const double val = p.ca * oldv[c][t] + p.cb * own + p.cc * R;
+                        bst_f64(rout[c], v8, soff, c == 0 ? val : sponge_relax(val, p.sponge));
+                    }
+                }
+        }
+        if (!more) break;
+        ++tile;
+        k = kN;
+        live = liveN;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int t = 0; t < KV; ++t) qB[c][t] = qN[c][t];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) geo[i] = geoN[i];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                fidx[f][tf] = fidxN[f][tf];
+                hP[f][tf] = hPN[f][tf]; huP[f][tf] = huPN[f][tf]; hvP[f][tf] = hvPN[f][tf];
+            }
+    }
+}
+
+} // namespace bdg_dev

@@ -225,6 +225,31 @@ hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+template <int MODE>
+hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const size_t ldsBytes = sizeof(double) * Mfma3Lds<kN>::DOUBLES;
+    auto kern = sw2d_stage_mfma3_kernel<kN, MODE>;
+    if (ldsBytes > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(ldsBytes));
+        if (e != hipSuccess) return e;
+    }
+    const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
+    const unsigned grid = std::min((ntiles + 3u) / 4u, 256u); // one four-wave workgroup per CU, one wave per SIMD
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t stageMfma3(int mode, const StageParams& p, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchMfma3<MODE_RHS>(p, stream);
+    case MODE_LSERK: return launchMfma3<MODE_LSERK>(p, stream);
+    case MODE_COMBINE: return launchMfma3<MODE_COMBINE>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 // matrix-core kernel with the momentum sources (operator image: MfmaOps2 + MT*KV tiles of F'); tracer = 1
 // launches the tracer pass instead (plain MfmaOps2 image), tracer = 2 the variant-B form (same image as the
 // sources), tracer = 3 sources and tracer fused (N <= 6). Orders above the unrolled kernels' range only.
@@ -348,7 +373,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, &stageMfma2Halo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
+                                      &stageMfma2, &stageMfma3, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

@@ -34,6 +34,17 @@ def main():
     into = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--into" else None
     stage = "sw2d_stage"
     summary = {"tag": tag, "kernel": None, "counters": {}, "launches_sampled": {}}
+    # what the collection ran: bench.py only quotes a summary that matches its workload and the device sources of today
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        summary["kernel_source_sha"] = bench.kernel_source_sha()
+        for line in open(os.path.join(out, f"prof_{tag}_warm.log")):
+            if line.startswith("{"):
+                cfg = json.loads(line)["config"]
+                summary["order"], summary["elements"] = cfg["order"], cfg["elements"]
+    except Exception as e:  # noqa: BLE001  (a summary without the tie is still a summary; bench.py then ignores it)
+        summary["kernel_source_sha_error"] = repr(e)
     for group in ("fetch", "write", "tcc", "sq", "grbm", "mfma"):
         vals, n, extra = counters(os.path.join(out, f"prof_{tag}_{group}"), stage)
         summary["counters"].update(vals)

@@ -633,8 +633,8 @@ def test_cpp_driver_sw2d_tidal_matches_oracle_replay(mode, coarse_mesh):
     assert abs(hvmax - np.abs(q[2]).max()) / np.abs(q[2]).max() < 1e-8
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
-@pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N4", "coarse_box_N6"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N4", "coarse_box_N6", "box2x2_N8"])
 def test_every_affine_kernel_variant_matches_the_reference_fixture(variant, case, monkeypatch):
     """The solver picks a kernel family by order and launch size (unrolled vector kernel for large
     N <= 5 launches, matrix-core kernels for small launches and N >= 6); BDG_SW2D_AFFINE_VARIANT pins
@@ -646,6 +646,9 @@ def test_every_affine_kernel_variant_matches_the_reference_fixture(variant, case
     scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
     for i in range(3):
         assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < RHS_TOL
+    rf = s.computeRHS(d["h"], d["hu"], d["hv"], filter=True)     # pre-filtered operator image
+    for i in range(3):
+        assert np.abs(rf[i] - d["Filter"] @ d[f"rhs{i + 1}"]).max() / scale < RHS_TOL
     o = oracle_from(d)
     dt = 0.5 * o.dt(d["h"], d["hu"], d["hv"], 0.65, int(d["order"]))
     s.setState(d["h"], d["hu"], d["hv"])
@@ -654,6 +657,36 @@ def test_every_affine_kernel_variant_matches_the_reference_fixture(variant, case
     ref = o.lserk4_stages(d["h"], d["hu"], d["hv"], zero, dt, 0, 7)
     for a, b in zip(s.getState(), ref[:3]):
         assert relmax(a, b) < STATE_TOL
+
+
+@pytest.mark.parametrize("order,nx,ny", [(5, 37, 29), (6, 30, 41), (7, 21, 19), (8, 33, 27)])
+def test_state_once_matrix_core_kernel_on_many_tiles(order, nx, ny, monkeypatch):
+    """The software-pipelined one-wave-per-SIMD schedule (sw2d_mfma3_kernel.hpp; BDG_SW2D_AFFINE_VARIANT=7) with several
+    tiles per wave, a ragged last tile and a shuffled element order, against the two-waves-per-SIMD schedule it replaces
+    (variant 6, itself pinned by the reference fixtures above): RHS, 11 LSERK4 stages and the midpoint RK2 + filter
+    driver step must agree to round-off (same arithmetic, same operator image)."""
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(nx, ny, shuffleSeed=4242)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    t = tables_from_nodes(nodes)
+    h, hu, hv = seeded_fields(t["x"], t["y"], seed=order)
+    out = {}
+    for variant in (6, 7):
+        monkeypatch.setenv("BDG_SW2D_AFFINE_VARIANT", str(variant))
+        s = sw2d.Sw2dSolver(tables=t, g=9.81, flags=sw2d.KEEP_ORDER)
+        rhs = s.computeRHS(h, hu, hv)
+        s.setState(h, hu, hv)
+        dt, _ = s.computeDt(0.4)
+        s.lserk4Stages(dt, 11)
+        st1 = s.getState()
+        s.setState(h, hu, hv)
+        s.stepRK2(dt, 3, filter=True)
+        out[variant] = (rhs, st1, s.getState())
+    for a, b in zip(out[6], out[7]):
+        for x, y in zip(a, b):
+            assert relmax(y, x) < 1e-13
+    assert relmax(out[7][1][1], hu) > 1e-6                        # the state moved
 
 
 @pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N6"])
