@@ -531,9 +531,10 @@ struct bdg_sw2d {
         p.ca = blitzdg::LSERK4::rk4a[st]; p.cb = blitzdg::LSERK4::rk4b[st]; p.cc = dtStage;
         p.haloRecv = recv; p.haloSend = send; p.haloSendOf = haloSendOf.p;
         p.haloOwned = numOwned; p.haloRows = nf * Np;
-        if (N >= 5) {
+        if (N >= 5) { // the kernel family the interior (and a single-domain run) uses: bit-identical arithmetic
             p.opsAffine = opsMfma2.p;
-            hipCheck(kt->stageMfma2Halo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
+            hipCheck(affineVariant == 6 ? kt->stageMfma2Halo(p, on) : kt->stageMfma3Halo(p, on),
+                     "sw2d boundary stage kernel <LSERK, halo>");
         } else {
             p.opsAffine = opsMfma.p;
             hipCheck(kt->stageMfmaHalo(p, on), "sw2d boundary stage kernel <LSERK, halo>");

@@ -30,6 +30,7 @@ struct KernelTable {
     // state-once schedule, one wave per SIMD with software-pipelined loads (same MfmaOps2 image; three fields, no
     // sources, no halo staging): sw2d_mfma3_kernel.hpp
     hipError_t (*stageMfma3)(int mode, const StageParams& p, hipStream_t stream);
+    hipError_t (*stageMfma3Halo)(const StageParams& p, hipStream_t stream); // MODE_LSERK with the halo staging folded in
     // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the
     // tracer-equation pass (plain MfmaOps2 image); tracer = 2: variant B (image as for the sources)
     hipError_t (*stageMfma2Src)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);

@@ -46,8 +46,13 @@ struct Mfma3Lds {
     static constexpr int DOUBLES = O::DOUBLES + 4 * TILE_DOUBLES;      // operator image + four waves' tiles
 };
 
-template <int N, int MODE>
+// HALO (MODE_LSERK, partition-boundary launches): the ghost exchange's pack and unpack folded in, as in
+// sw2d_stage_mfma_kernel -- a neighbour trace that lives in a ghost slot is read from the received record, and the new
+// state of an element is also written to its (up to three) send records. Same arithmetic as HALO = false, so a
+// partitioned run reproduces the single-domain run bit for bit.
+template <int N, int MODE, bool HALO = false>
 __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StageParams p) {
+    static_assert(!HALO || MODE == MODE_LSERK, "halo staging is folded into LSERK stages only");
     using E = Elem<N>;
     using O = MfmaOps2<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
@@ -82,6 +87,8 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         rres[c] = plane_rsrc((MODE == MODE_LSERK ? p.res : p.qin) + c * plane, planeBytes);
     }
     const __amdgpu_buffer_rsrc_t rgeo = plane_rsrc(p.ageo, 13u * ld8), ridx = plane_rsrc(p.vmapP, 3u * Nfp * ld4);
+    // received ghost records [ghost][field][node] (HALO); the descriptor is never used otherwise
+    const __amdgpu_buffer_rsrc_t rrecv = plane_rsrc(HALO ? p.haloRecv : p.ageo, 0xffffffffu);
 
     // element of this lane in tile `tl` (padding lanes recompute the last element and store nothing)
     auto elementOf = [&](unsigned tl, bool& live) {
@@ -113,7 +120,17 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         for (int tf = 0; tf < KF; ++tf) {
             const int n = 4 * tf + static_cast<int>(q);
             const int id = n < Nfp ? ix[f][tf] : 0;
-            const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
+            const unsigned idp = static_cast<unsigned>(id < 0 ? -(id + 1) : id), o8 = idp * 8u;
+            if constexpr (HALO) {
+                const unsigned row = idp / static_cast<unsigned>(ld), slot = idp - row * static_cast<unsigned>(ld);
+                if (slot >= static_cast<unsigned>(p.haloOwned)) { // the neighbour's record as it arrived: [field][node]
+                    const unsigned rec8 = ((slot - static_cast<unsigned>(p.haloOwned)) * static_cast<unsigned>(p.haloRows) + row) * 8u;
+                    a[f][tf] = bld_f64(rrecv, rec8, 0u);
+                    b[f][tf] = bld_f64(rrecv, rec8, static_cast<unsigned>(Np) * 8u);
+                    c3[f][tf] = bld_f64(rrecv, rec8, static_cast<unsigned>(2 * Np) * 8u);
+                    continue;
+                }
+            }
             a[f][tf] = bld_f64(rq[0], o8, 0u);
             b[f][tf] = bld_f64(rq[1], o8, 0u);
             c3[f][tf] = bld_f64(rq[2], o8, 0u);
@@ -277,6 +294,13 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         // ---- stage update / output: node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3); stores of the
         //      padding rows fall outside the plane and are dropped by the bounds check, padding lanes store nothing
         if (live) {
+            int sendRec[3] = {-1, -1, -1};
+            if constexpr (HALO) {
+                const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
+                sendRec[0] = p.haloSendOf[b3];
+                sendRec[1] = p.haloSendOf[b3 + 1];
+                sendRec[2] = p.haloSendOf[b3 + 2];
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -289,8 +313,17 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                         bst_f64(rout[c], v8, soff, R);
                     } else if constexpr (MODE == MODE_LSERK) {
                         const double n1 = p.ca * oldv[c][t] + p.cc * R;
+                        const double qn = own + p.cb * n1;
                         bst_f64(rres[c], v8, soff, n1);
-                        bst_f64(rout[c], v8, soff, own + p.cb * n1);
+                        bst_f64(rout[c], v8, soff, qn);
+                        if constexpr (HALO) {
+                            if (m < Np) {
+#pragma unroll
+                                for (int sr = 0; sr < 3; ++sr)
+                                    if (sendRec[sr] >= 0)
+                                        p.haloSend[static_cast<size_t>(sendRec[sr]) * p.haloRows + c * Np + m] = qn;
+                            }
+                        }
                     } else {
                         const double val = p.ca * oldv[c][t] + p.cb * own + p.cc * R;
                         bst_f64(rout[c], v8, soff, c == 0 ? val : sponge_relax(val, p.sponge));

@@ -241,6 +241,21 @@ hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// one LSERK4 stage of the partition-boundary elements with the halo staging folded in, state-once schedule
+hipError_t stageMfma3Halo(const StageParams& p, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    const size_t ldsBytes = sizeof(double) * Mfma3Lds<kN>::DOUBLES;
+    auto kern = sw2d_stage_mfma3_kernel<kN, MODE_LSERK, true>;
+    if (ldsBytes > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(ldsBytes));
+        if (e != hipSuccess) return e;
+    }
+    const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
+    hipLaunchKernelGGL(kern, dim3(std::min((ntiles + 3u) / 4u, 256u)), dim3(256), ldsBytes, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t stageMfma3(int mode, const StageParams& p, hipStream_t stream) {
     switch (mode) {
     case MODE_RHS: return launchMfma3<MODE_RHS>(p, stream);
@@ -373,7 +388,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, &stageMfma2Halo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, &stageMfma3, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
+                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;
 }
