@@ -63,6 +63,16 @@ def main():
                                            "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
                                            "stddev_ns": float(r["StdDev"]), "percent_of_gpu_time": float(r["Percentage"])}
                 break
+    # the timed region of bench.py = the LAST 200 stage launches of the traced run (before them: the untimed
+    # clock-ramp blocks and the warm-up, during which a fresh box is still raising its clocks)
+    traces = glob.glob(os.path.join(out, f"prof_{tag}_trace", "*", "*_kernel_trace.csv"))
+    if traces:
+        durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                for r in csv.DictReader(open(traces[0])) if stage in r["Kernel_Name"]]
+        durs = [d for _, d in sorted(durs)][-200:]
+        if durs:
+            summary["kernel_trace_timed_region"] = {"launches": len(durs), "avg_ns": sum(durs) / len(durs),
+                                                    "min_ns": min(durs), "max_ns": max(durs)}
     c = summary["counters"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         summary["hbm_traffic_per_launch"] = {
