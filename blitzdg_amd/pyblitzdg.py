@@ -235,12 +235,18 @@ class TriangleNodesProvisioner:
         if h:
             lib.bdg_trinodes_destroy(h)
 
+    #: bumped by every method that changes a table a device solver may have copied (filter, BC lists, coordinates,
+    #: repaired metric terms): caches of device images key on it (blitzdg_amd.sw2d.computeRHS)
+    _tables_version = 0
+
     def buildFilter(self, Nc, s):
         check(lib.bdg_trinodes_build_filter(self._h, float(Nc), int(s)))
+        self._tables_version += 1
 
     def buildBCHash(self, bcType):
         b = C.as_i32(bcType).reshape(-1)
         check(lib.bdg_trinodes_build_bchash(self._h, C.ptr(b), b.size))
+        self._tables_version += 1
 
     def bedSlopes(self, H):
         """(Hx, Hy) as the variant-B driver builds them (reference src/sw2d/main.cpp:128-133)."""
@@ -281,6 +287,7 @@ class TriangleNodesProvisioner:
         _, Np, _, K = self._dims()
         xa, ya = C.as_f64(x, (Np, K), "x"), C.as_f64(y, (Np, K), "y")
         check(lib.bdg_trinodes_set_coordinates(self._h, C.ptr(xa), C.ptr(ya)))
+        self._tables_version += 1
 
     def buildGaussFaceNodes(self, NGauss):
         """reference src/TriangleNodesProvisioner.cpp:207-381"""
@@ -292,7 +299,7 @@ class TriangleNodesProvisioner:
         """reference src/TriangleNodesProvisioner.cpp:81-205 (also recomputes the nodal J, rx, ry, sx, sy)"""
         h = c_void_p()
         check(lib.bdg_trinodes_build_cubature_volume_mesh(self._h, int(NCubature), byref(h)))
-        self._tables_version = getattr(self, "_tables_version", 0) + 1
+        self._tables_version += 1
         return CubatureContext2D(h)
 
     def dgContext(self):

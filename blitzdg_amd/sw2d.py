@@ -248,11 +248,15 @@ _solver_cache = weakref.WeakKeyDictionary()
 
 def computeRHS(h, hu, hv, g, triangleNodesProvisioner, filter=False, device=0):
     """Drop-in for ``blitzdg::sw2d::computeRHS(h, hu, hv, g, nodes, RHS1, RHS2, RHS3)``: returns
-    (RHS1, RHS2, RHS3). The device image of the provisioner's tables is cached per provisioner."""
+    (RHS1, RHS2, RHS3). The device image of the provisioner's tables is cached per provisioner and rebuilt
+    when the provisioner's tables change (buildFilter, buildBCHash, setCoordinates, buildCubatureVolumeMesh)."""
     key = triangleNodesProvisioner
     entry = _solver_cache.get(key)
-    if entry is None or entry[0] != (float(g), int(device)):
-        entry = ((float(g), int(device)), Sw2dSolver(nodes=key, g=g, device=device))
+    # the reference reads the provisioner on every call: a later buildFilter / buildBCHash / setCoordinates must
+    # not be answered from a stale device image
+    stamp = (float(g), int(device), getattr(key, "_tables_version", 0))
+    if entry is None or entry[0] != stamp:
+        entry = (stamp, Sw2dSolver(nodes=key, g=g, device=device))
         _solver_cache[key] = entry
     return entry[1].computeRHS(h, hu, hv, filter=filter)
 

@@ -337,7 +337,12 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
                        const int* send_start, const int* send_count, const int* recv_start,
                        const int* recv_count, int num_peers);
 /* num_stages LSERK4 stages with the ghost exchange overlapped with the interior elements:
- * pack -> {grouped ncclSend/ncclRecv on the comm stream || interior kernel} -> unpack -> boundary. */
+ * pack -> {grouped ncclSend/ncclRecv on the comm stream || interior kernel} -> unpack -> boundary.
+ * Ghost elements are inputs of a stage only: after this call (and after bdg_sw2d_group_lserk4_stages)
+ * the ghost columns returned by bdg_sw2d_get_state / read by bdg_sw2d_rhs_resident and the output
+ * functions are UNDEFINED -- they hold whatever an earlier stage received, or, where the boundary kernel
+ * reads the received records directly, their initial values. Owned columns are exact. The next
+ * exchanged stage refreshes the ghosts before it reads them. */
 int bdg_sw2d_lserk4_stages_exchanged(bdg_sw2d* s, double dt, int num_stages);
 /* In-process alternative to RCCL: all parts of the split are handles of THIS process (one per GPU
  * of the node, or several on one GPU). bdg_sw2d_local_peers takes the same neighbour tables as

@@ -27,6 +27,9 @@ Writes
                             swhelpers.rhs.sw2dComputeRHS_curved (swhelpers/rhs.py:6-176) on deformed
                             meshes; the Gauss-face and cubature contexts it reads are built by THIS
                             repo's buildGaussFaceNodes / buildCubatureVolumeMesh and stored with it
+  sw2d_rhsB_degenerate_<case>.npz
+                            the same function on a state (uniform depth and speed, flat bed, Coriolis only)
+                            for which the C++ driver's variant B must give the same RHS
   advec1d_rhs_N4_K100.npz   advec1dComputeRHS(u, c, nodes1d) of the reference SCRIPT advec1d.py:12-39
   sw2d_rhsC_<case>.npz      sw2dComputeRHS(h,hu,hv,hN,g,H,f,ctx) of the reference SCRIPT sw2d.py:37-146
                             ("variant C"), its two function definitions compiled on their own
@@ -158,6 +161,42 @@ def rhs4_case(name, mesh, order, g=9.81):
                         H=H, zx=zx, zy=zy, f=f, CD=CD, rhs1=r[0], rhs2=r[1], rhs3=r[2], rhs4=r[3], **tabs)
     print(f"sw2d_rhs4_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} |rhs|max="
           f"{max(abs(a).max() for a in r):.6g}")
+
+
+def rhsB_degenerate_case(name, mesh, order, g=9.81, f=0.05):
+    """Variant B (src/sw2d/main.cpp:279-484) where it degenerates to something the reference's Python RHS can
+    produce: flat bed (star states are the identity, no bed-slope source), no open boundary, no drag, and a state
+    with |u| and h uniform -- h = 10, (u, v) = 0.8 (cos theta, sin theta) -- so that the speed |u| + sqrt(g h) is the
+    same at every face node and the per-face Lax-Friedrichs speed of the Python RHS equals variant B's one global
+    speed (to the last bits of the sqrt). Output of swhelpers.rhs.sw2dComputeRHS with hN = 0, CD = 0, zx = zy = 0."""
+    import blitzdg_amd.pyblitzdg as dg
+    sys.path.insert(0, REF)
+    if not hasattr(np, "float"):
+        np.float = float
+    from swhelpers.rhs import sw2dComputeRHS
+
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    ctx = nodes.dgContext()
+    tabs = {k: getattr(ctx, k) for k in
+            ("Dr", "Ds", "Lift", "rx", "sx", "ry", "sy", "nx", "ny", "Fscale", "vmapM", "vmapP", "x", "y")}
+    tabs["Filter"] = ctx.filter
+    bcmap = ctx.BCmap
+    tabs["mapW"] = np.array(bcmap.get(3, []), dtype=np.int32)
+    x, y = tabs["x"], tabs["y"]
+    theta = 1.3 * x + 0.7 * y * y
+    h = 10.0 + 0 * x
+    hu, hv = h * 0.8 * np.cos(theta), h * 0.8 * np.sin(theta)
+    ref_ctx = types.SimpleNamespace(BCmap=bcmap, nx=tabs["nx"], ny=tabs["ny"], rx=tabs["rx"], sx=tabs["sx"],
+                                    ry=tabs["ry"], sy=tabs["sy"], Dr=tabs["Dr"], Ds=tabs["Ds"],
+                                    numFacePoints=ctx.numFacePoints, numElements=ctx.numElements,
+                                    numFaces=ctx.numFaces, Lift=tabs["Lift"], Fscale=tabs["Fscale"])
+    z = np.zeros_like(h)
+    r = sw2dComputeRHS(h, hu, hv, z.copy(), z, z, g, h.copy(), f, 0.0, ref_ctx, tabs["vmapM"], tabs["vmapP"])
+    np.savez_compressed(os.path.join(HERE, f"sw2d_rhsB_degenerate_{name}.npz"), order=order, g=g, f=f, h=h, hu=hu, hv=hv,
+                        H=h.copy(), rhs1=r[0], rhs2=r[1], rhs3=r[2], **tabs)
+    print(f"sw2d_rhsB_degenerate_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} |rhs|max="
+          f"{max(abs(a).max() for a in r[:3]):.6g}")
 
 
 def bump_deformation(x, y, centre, radius, amp):
@@ -325,6 +364,17 @@ def main():
     rhsC_case("box6x5_shuffled_N6", shuffled, 6)
     advec1d_case()
     curved_cases()
+    degenerate_b_cases()
+
+
+def degenerate_b_cases():
+    import blitzdg_amd.pyblitzdg as dg
+    coarse = dg.MeshManager()
+    coarse.readMesh(os.path.join(HERE, "coarse_box.msh"))
+    shuffled = dg.MeshManager()
+    shuffled.buildBoxMesh(6, 5, shuffleSeed=12345)
+    rhsB_degenerate_case("coarse_box_N3", coarse, 3)
+    rhsB_degenerate_case("box6x5_shuffled_N6", shuffled, 6)
 
 
 def curved_cases():
@@ -348,5 +398,7 @@ def curved_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "curved":
         curved_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "degenerate_b":
+        degenerate_b_cases()
     else:
         main()

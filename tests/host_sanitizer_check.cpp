@@ -1,10 +1,13 @@
 // Sanitizer run of the host-side setup path (no GPU): mesh reader/writer, connectivity, partition,
-// provisioners, filter, bed slopes, split elements, vtu writer, advec1d.
+// provisioners, filter, bed slopes, split elements, vtu writer, advec1d, Gauss-face / cubature contexts, and the
+// reshape helpers on the cases of the reference's BlitzHelpersTests.cpp:38-96 (exit code 1 on a mismatch).
 #include "blitzdg/Advec1d.hpp"
+#include "blitzdg/BlitzHelpers.hpp"
 #include "blitzdg/MeshManager.hpp"
 #include "blitzdg/Nodes1DProvisioner.hpp"
 #include "blitzdg/TriangleNodesProvisioner.hpp"
 #include "blitzdg/VtkOutputter.hpp"
+#include <cmath>
 #include <cstdio>
 #include <iostream>
 using namespace blitzdg;
@@ -29,6 +32,35 @@ int main(int argc, char** argv) {
         out.writeFieldToFile("/tmp/asan_f.vtu", f, "f");
         index_vector_type bc = m2.get_BCType();
         nodes.buildBCHash(bc);
+    }
+    {   // reshapeMatTo1D / reshape1DToMat: Should_Convert_Full_Matrix_To_POD, Should_Convert_POD_To_Full_Matrix
+        const double rowwise[25] = {2, 3, 0, 0, 0, 3, 0, 4, 0, 6, 0, -1, -3, 2, 0, 0, 0, 1, 0, 0, 0, 4, 2, 0, 1};
+        const double colwise[25] = {2, 3, 0, 0, 0, 3, 0, -1, 0, 4, 0, 4, -3, 1, 2, 0, 0, 2, 0, 0, 0, 6, 0, 0, 1};
+        real_matrix_type mat(5, 5), back(5, 5);
+        reshape1DToMat(rowwise, mat);
+        real_vector_type pod(25);
+        reshapeMatTo1D(mat, pod.data());
+        for (int i = 0; i < 25; ++i) if (pod(i) != rowwise[i]) return 1;
+        reshapeMatTo1D(mat, pod.data(), false);
+        for (int i = 0; i < 25; ++i) if (pod(i) != colwise[i]) return 1;
+        reshape1DToMat(pod.data(), back, false);
+        for (int i = 0; i < 5; ++i) for (int jj = 0; jj < 5; ++jj) if (back(i, jj) != mat(i, jj)) return 1;
+        reshape1DToMat(rowwise, back, false);                       // column-wise read of the row-wise array = transpose
+        for (int i = 0; i < 5; ++i) for (int jj = 0; jj < 5; ++jj) if (back(i, jj) != mat(jj, i)) return 1;
+    }
+    {   // Gauss-face and cubature contexts on a deformed copy of the mesh
+        TriangleNodesProvisioner nodes(4, m2);
+        const DGContext2D ctx = nodes.get_DGContext();
+        real_matrix_type x = ctx.x(), y = ctx.y();
+        for (index_type i = 0; i < x.rows(); ++i)
+            for (index_type k = 0; k < x.cols(); ++k) y(i, k) += 0.03 * (1 - x(i, k) * x(i, k)) * (1 - y(i, k) * y(i, k));
+        nodes.setCoordinates(x.data(), y.data());
+        const GaussFaceContext2D g = nodes.buildGaussFaceNodes(10);
+        const CubatureContext2D c = nodes.buildCubatureVolumeMesh(15);
+        double area = 0;
+        for (index_type i = 0; i < c.W().rows(); ++i)
+            for (index_type k = 0; k < c.W().cols(); ++k) area += c.W()(i, k);
+        if (g.NGauss() != 10 || c.NumCubaturePoints() != 64 || std::fabs(area - 4.0) > 1e-10) return 1;
     }
     MeshManager box;
     box.buildBoxMesh(37, 23, -1, 1, -1, 1, 12345);

@@ -196,6 +196,23 @@ def test_variant_b_oracle_with_local_speed_reproduces_the_reference_fixture(case
         assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < 1e-14
 
 
+@pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N6"])
+def test_variant_b_oracle_with_global_speed_reproduces_the_reference_on_a_uniform_speed_state(case):
+    """Where variant B degenerates to what the reference's Python RHS computes -- flat bed, no open boundary, no
+    drag, and a state of uniform depth and speed, for which the ONE global Lax-Friedrichs speed of the C++ driver
+    (src/sw2d/main.cpp:414) equals every face's own maximum -- the restatement WITH its global speed reproduces the
+    reference function's output (tests/golden/sw2d_rhsB_degenerate_*.npz; Coriolis on)."""
+    import os
+    from conftest import GOLDEN
+    from oracle import oracle_np as onp
+    d = np.load(os.path.join(GOLDEN, f"sw2d_rhsB_degenerate_{case}.npz"))
+    z = np.zeros_like(d["h"])
+    r = onp.sw2d_rhs_b(d["h"], d["hu"], d["hv"], d["H"], z, z, float(d["g"]), float(d["f"]), 0.0, 0.0, d, ())
+    scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
+    for c in range(3):
+        assert np.abs(r[c] - d[f"rhs{c + 1}"]).max() / scale < 1e-14
+
+
 def test_variant_b_sources_agree_with_variant_d_fixture():
     """Bed slope and Coriolis of variant B (RHS2 += g h Hx + f hv, RHS3 += g h Hy - f hu) are variant
     D's with zx = -Hx, zy = -Hy (drag differs by D's sign quirk, so CD = 0 here); the tracer is ignored."""

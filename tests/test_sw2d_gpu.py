@@ -527,6 +527,25 @@ def test_variant_b_rhs_vs_oracle(order, coarse_mesh):
     del col
 
 
+@pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N6"])
+def test_variant_b_matches_the_reference_function_where_it_degenerates_to_it(case):
+    """The HIP variant-B path (global Lax-Friedrichs speed, star states, Coriolis source) against the output of the
+    reference's own Python RHS on a state for which the two coincide: flat bed, no open boundary, no drag, uniform
+    depth and speed (tests/golden/sw2d_rhsB_degenerate_*.npz, made by the imported reference function). The unrolled
+    kernel (N=3) and the matrix-core kernel (N=6)."""
+    import os
+    from conftest import GOLDEN
+    d = np.load(os.path.join(GOLDEN, f"sw2d_rhsB_degenerate_{case}.npz"))
+    s = solver_from_case(d)
+    z = np.zeros_like(d["h"])
+    s.enableVariantB(d["H"], z, z, mapO=(), CD=0.0, f=float(d["f"]))
+    r = s.computeRHS(d["h"], d["hu"], d["hv"])
+    scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
+    for i in range(3):
+        assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < RHS_TOL
+    assert abs(s.globalSpeed - (0.8 + np.sqrt(float(d["g"]) * 10.0))) < 1e-12 * s.globalSpeed
+
+
 @pytest.mark.parametrize("order,shuffle", [(2, 0), (4, 11)])
 def test_variant_b_ssprk2_driver_loop_vs_oracle(order, shuffle):
     """The driver's loop body (main.cpp:211-236): Heun with both evaluations at the old time level,
