@@ -177,6 +177,8 @@ _SIGNATURES = {
     "bdg_comm_unique_id": (c_int, [_P, c_int]),
     "bdg_sw2d_comm_init": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int]),
     "bdg_sw2d_lserk4_stages_exchanged": (c_int, [_P, c_double, c_int]),
+    "bdg_sw2d_step_rk2_exchanged": (c_int, [_P, c_double, c_int, c_int]),
+    "bdg_sw2d_step_ssprk2_exchanged": (c_int, [_P, c_double, c_int, c_int, c_double]),
     "bdg_sw2d_local_peers": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int]),
     "bdg_sw2d_group_lserk4_stages": (c_int, [POINTER(_P), c_int, c_double, c_int]),
     "bdg_sw2d_compute_dt_global": (c_int, [_P, c_double, POINTER(c_double), POINTER(c_double)]),

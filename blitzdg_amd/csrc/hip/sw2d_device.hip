@@ -354,7 +354,27 @@ struct bdg_sw2d {
         if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < kSmallLaunch[N]) variant = 5;
         if (variantB) {
             vb.tide = tideAt(timeNow);
-            if (fastSources) {
+            if (lamExternal) {
+                // partitioned run: the global speed of this state was reduced over all ranks into lamBuf beforehand
+                // (globalSpeedOf); every kernel family runs without its own speed pass
+                vb.lam = lamBuf.p;
+                vb.lamNext = nullptr;
+                lamStateFor = nullptr;
+                if (fastSources) {
+                    p.opsAffine = opsAffine.p;
+                    hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 2, filter ? filterT.p : nullptr, st), what);
+                } else if (mfmaSources) {
+                    bdg_dev::PhysParams ph{};
+                    ph.sx = vb.Hx; ph.sy = vb.Hy; ph.fconst = vb.fcor; ph.cd = vb.cd;
+                    ph.slope = 1.0; ph.dragSign = -1.0;
+                    ph.H = vb.H; ph.obc = vb.obc; ph.lam = lamBuf.p; ph.spongeField = vb.sponge; ph.tide = vb.tide;
+                    p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
+                    hipCheck(kt->stageMfma2Src(mode, p, ph, 2, st), what);
+                } else {
+                    p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
+                    hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 6, nullptr, st), what);
+                }
+            } else if (fastSources) {
                 // The unrolled kernel also reduces the global speed of the state it writes (for the tide value
                 // the next evaluation is expected to see). If this launch reads exactly that state at exactly
                 // that tide over the whole mesh, the separate speed pass is skipped.
@@ -447,6 +467,7 @@ struct bdg_sw2d {
         }
     }
     bool fastSources = false; // variants B/C/D on the unrolled kernels instead of the rolled ones
+    bool lamExternal = false; // variant B, partitioned: lamBuf holds the all-rank speed of the state about to be evaluated
     // up to this order the unrolled source-term kernels are used, above it the matrix-core ones
     static constexpr int kUnrolledSourcesMaxOrder = 4;
     DevBuf<double> filterT;   // [m][i] = Filter[i][m], for filtered source terms
@@ -498,22 +519,73 @@ struct bdg_sw2d {
     }
     double dtStage = 0.0;
 
-    void launchPack(double* buf, hipStream_t on = nullptr) {
+    // `state`: the planes whose boundary elements are packed / whose ghost columns are filled (default: the current state)
+    void launchPack(double* buf, hipStream_t on = nullptr, const double* state = nullptr) {
         if (numSend == 0) return;
         const int rows = nf * Np;
         const long long n = static_cast<long long>(numSend) * rows;
         hipLaunchKernelGGL(bdg_dev::halo_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
-                           on ? on : stream, qcur, buf, sendSlots.p, numSend, rows, ld);
+                           on ? on : stream, state ? state : qcur, buf, sendSlots.p, numSend, rows, ld);
         hipCheck(hipGetLastError(), "halo_pack_kernel");
     }
-    void launchUnpack(const double* buf, hipStream_t on = nullptr) {
+    void launchUnpack(const double* buf, hipStream_t on = nullptr, double* state = nullptr) {
         const int ghosts = K - numOwned;
         if (ghosts == 0) return;
         const int rows = nf * Np;
         const long long n = static_cast<long long>(ghosts) * rows;
         hipLaunchKernelGGL(bdg_dev::halo_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0,
-                           on ? on : stream, qcur, buf, numOwned, ghosts, rows, ld);
+                           on ? on : stream, state ? state : qcur, buf, numOwned, ghosts, rows, ld);
         hipCheck(hipGetLastError(), "halo_unpack_kernel");
+    }
+
+    // ---- plain (not overlapped) exchange for the steppers whose RHS needs more than the neighbours' traces of the
+    //      previous stage: every evaluation of the midpoint / Heun schemes reads another state, and variant B also
+    //      needs ONE Lax-Friedrichs speed over all ranks (reference src/sw2d/main.cpp:414) before any element starts.
+    void exchangeGhostsOf(double* state) {
+        if (!comm) throw arg_error("no communicator: call bdg_sw2d_comm_init first");
+        const int rows = nf * Np;
+        launchPack(sendBuf.p, stream, state);
+        if (!peers.empty()) {
+            RcclApi& nc = rccl();
+            ncclCheck(nc.GroupStart(), "ncclGroupStart");
+            for (const Peer& pr : peers) {
+                if (pr.recvCount > 0)
+                    ncclCheck(nc.Recv(recvBuf.p + static_cast<size_t>(pr.recvStart) * rows, static_cast<size_t>(pr.recvCount) * rows,
+                                      ncclDouble, pr.rank, comm, stream), "ncclRecv");
+                if (pr.sendCount > 0)
+                    ncclCheck(nc.Send(sendBuf.p + static_cast<size_t>(pr.sendStart) * rows, static_cast<size_t>(pr.sendCount) * rows,
+                                      ncclDouble, pr.rank, comm, stream), "ncclSend");
+            }
+            ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
+        }
+        launchUnpack(recvBuf.p, stream, state);
+    }
+    // variant B: speed of `state` over this rank's owned elements (their '+' traces include the ghosts just received),
+    // then the maximum over all ranks, left in lamBuf on the device: one 8-byte all-reduce per RHS evaluation
+    void globalSpeedOf(const double* state) {
+        bdg_dev::StageParams p = baseParams();
+        p.qin = state;
+        vb.tide = tideAt(timeNow);
+        vb.lam = lamBuf.p;
+        hipCheck(kt->stageVb(bdg_dev::MODE_RHS, p, vb, vbPartials.p, lamBuf.p, 4, nullptr, stream), "sw2d_vb_speed_kernel");
+        if (comm && commWorld > 1)
+            ncclCheck(rccl().AllReduce(lamBuf.p, lamBuf.p, 1, ncclDouble, ncclMax, comm, stream), "ncclAllReduce");
+    }
+    // one evaluation of a partitioned run: ghosts of `state`, the all-rank speed (variant B), then fn launches the stage
+    template <typename Fn>
+    void evaluateExchanged(double* state, Fn&& fn) {
+        exchangeGhostsOf(state);
+        if (variantB) {
+            globalSpeedOf(state);
+            lamExternal = true;
+        }
+        try {
+            fn();
+        } catch (...) {
+            lamExternal = false;
+            throw;
+        }
+        lamExternal = false;
     }
 
     // True when the partition-boundary launch of an exchanged stage can do the halo staging itself (three-field
@@ -560,6 +632,10 @@ struct bdg_sw2d {
         if (numStages <= 0) return;
         const int rows = nf * Np;
         dtStage = dt;
+        if (variantB) { // the all-rank speed has to exist before any element of the stage starts: no overlap to be had
+            for (int i = 0; i < numStages; ++i) evaluateExchanged(qcur, [&] { launchLserkStage(2); });
+            return;
+        }
         // chain B starts after everything already queued on A (state upload, earlier steps)
         hipCheck(hipEventRecord(evA[1], stream), "hipEventRecord");
         hipCheck(hipStreamWaitEvent(commStream, evA[1], 0), "hipStreamWaitEvent");
@@ -626,6 +702,37 @@ struct bdg_sw2d {
         p.ca = 1.0; p.cb = 0.0; p.cc = dt;
         nextEvalTime = timeNow + dt;
         launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>");
+        std::swap(qcur, qalt);
+        timeNow += dt;
+    }
+
+    // The same two schemes in a partitioned run: each evaluation first refreshes the ghost columns of the state it reads
+    // (and, variant B, reduces the Lax-Friedrichs speed over all ranks).
+    void launchRk2StepExchanged(double dt, bool filter) {
+        if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
+        bdg_dev::StageParams p = baseParams();
+        p.qin = qcur; p.qbase = qcur; p.qout = aux.p;
+        p.ca = 1.0; p.cb = 0.0; p.cc = 0.5 * dt;
+        nextEvalTime = timeNow;
+        evaluateExchanged(qcur, [&] { launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>"); });
+        p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
+        p.ca = 1.0; p.cb = 0.0; p.cc = dt;
+        nextEvalTime = timeNow + dt;
+        evaluateExchanged(aux.p, [&] { launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>"); });
+        std::swap(qcur, qalt);
+        timeNow += dt;
+    }
+    void launchSspRk2StepExchanged(double dt, bool filter, double spongeCoeff) {
+        bdg_dev::StageParams p = baseParams();
+        p.sponge = spongeCoeff;
+        p.qin = qcur; p.qbase = qcur; p.qout = aux.p;
+        p.ca = 1.0; p.cb = 0.0; p.cc = dt;
+        nextEvalTime = timeNow;
+        evaluateExchanged(qcur, [&] { launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>"); });
+        p.qin = aux.p; p.qbase = qcur; p.qout = qalt;
+        p.ca = 0.5; p.cb = 0.5; p.cc = 0.5 * dt;
+        nextEvalTime = timeNow + dt;
+        evaluateExchanged(aux.p, [&] { launchStage(bdg_dev::MODE_COMBINE, filter, p, "sw2d stage kernel <COMBINE>"); });
         std::swap(qcur, qalt);
         timeNow += dt;
     }
@@ -1261,8 +1368,9 @@ int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* d) {
             throw arg_error("bdg_sw2d_enable_variant_b: the solver was created with tracer / variant-D sources");
         if (!s->affine)
             throw arg_error("bdg_sw2d_enable_variant_b: implemented for straight-sided (affine) geometry only");
-        if (s->numOwned != s->K || s->comm)
-            throw arg_error("bdg_sw2d_enable_variant_b: not available on a partitioned solver (global wave speed)");
+        // partitioned solvers: allowed -- their steppers are the *_exchanged ones, which reduce the global speed over all
+        // ranks before each evaluation (evaluateExchanged); the in-process group transport has no such reduction
+        if (s->localGroup) throw arg_error("bdg_sw2d_enable_variant_b: not available with the in-process group transport");
         if (d->num_out < 0 || (d->num_out > 0 && !d->mapO)) throw arg_error("bdg_sw2d_enable_variant_b: bad open-boundary list");
         if (!(d->tide_period > 0.0) && d->num_out > 0) throw arg_error("bdg_sw2d_enable_variant_b: tide_period must be > 0");
         const size_t nFaceNodes = static_cast<size_t>(s->NFN) * s->K;
@@ -1449,6 +1557,24 @@ int bdg_sw2d_step_ssprk2(bdg_sw2d* s, double dt, int num_steps, int filter, doub
     });
 }
 
+int bdg_sw2d_step_rk2_exchanged(bdg_sw2d* s, double dt, int num_steps, int filter) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_step_rk2_exchanged");
+        if (num_steps < 0) throw arg_error("bdg_sw2d_step_rk2_exchanged: num_steps < 0");
+        s->use();
+        for (int i = 0; i < num_steps; ++i) s->launchRk2StepExchanged(dt, filter != 0);
+    });
+}
+
+int bdg_sw2d_step_ssprk2_exchanged(bdg_sw2d* s, double dt, int num_steps, int filter, double sponge_coeff) {
+    return guard([&] {
+        requireSolver(s, "bdg_sw2d_step_ssprk2_exchanged");
+        if (num_steps < 0) throw arg_error("bdg_sw2d_step_ssprk2_exchanged: num_steps < 0");
+        s->use();
+        for (int i = 0; i < num_steps; ++i) s->launchSspRk2StepExchanged(dt, filter != 0, sponge_coeff);
+    });
+}
+
 int bdg_sw2d_compute_dt(bdg_sw2d* s, double cfl, double* dt, double* eta_max) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_compute_dt");
@@ -1514,7 +1640,6 @@ int bdg_sw2d_time_lserk4_stages(bdg_sw2d* s, double dt, int num_stages, float* m
 int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const int* send_elements, int num_send) {
     return guard([&] {
         requireSolver(s, "bdg_sw2d_set_partition");
-        if (s->variantB) throw arg_error("bdg_sw2d_set_partition: not available with variant B (global wave speed)");
         if (!s->permHost.empty())
             throw arg_error("bdg_sw2d_set_partition: the solver renumbered its elements; create it with BDG_SW2D_KEEP_ORDER");
         if (num_interior < 0 || num_interior > num_owned || num_owned > s->K || num_send < 0 ||

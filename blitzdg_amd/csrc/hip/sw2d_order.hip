@@ -331,14 +331,16 @@ template <int MODE>
 hipError_t launchVb(const StageParams& p, const VbParams& vp, double* partials, double* lam, int unrolled,
                     const double* filterT, hipStream_t stream) {
     if (p.kend <= p.kbegin) return hipSuccess;
-    if (unrolled != 2) { // 2: vp.lam already holds the speed of this state (accumulated by the launch that wrote it)
+    // 2, 6: vp.lam already holds the speed of this state (2: accumulated by the launch that wrote it, unrolled kernel;
+    // 6: reduced over all ranks of a partitioned run beforehand, rolled kernel)
+    if (unrolled != 2 && unrolled != 6) {
         const unsigned nblocks = static_cast<unsigned>((p.kend - p.kbegin + 255) / 256);
         hipLaunchKernelGGL((sw2d_vb_speed_kernel<kN>), dim3(nblocks), dim3(256), 0, stream, p, vp, partials);
         hipLaunchKernelGGL((sw2d_vb_speed_reduce_kernel<kN>), dim3(1), dim3(256), 0, stream, partials, static_cast<int>(nblocks), lam);
     }
     if (unrolled == 4) return hipGetLastError(); // speed pass only: the stage pass is the matrix-core kernel
     if constexpr (!kNoUnrolledSources) {
-        if (unrolled) {
+        if (unrolled && unrolled != 6) {
             const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kUnrolledBlock - 1) / kUnrolledBlock);
             if (filterT)
                 hipLaunchKernelGGL((sw2d_stage_vb_unrolled_kernel<kN, MODE, true>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, vp, filterT);

@@ -188,7 +188,8 @@ class NativeDistributedSw2d:
     ncclSend/ncclRecv on a communication stream, overlapped with the interior elements, whole
     stage loops issued by one C call (no per-stage Python). PyTorch is not involved."""
 
-    def __init__(self, plan, order, g=9.81, device=0, unique_id=None, loopback=False):
+    def __init__(self, plan, order, g=9.81, device=0, unique_id=None, loopback=False, filter_args=None, fields=3,
+                 sources=None):
         """loopback=True: schedule rehearsal on ONE GPU -- this process computes `plan.rank`'s share
         of a `plan.world`-way split, and every neighbour exchange is a send-to-self of the same size
         (ghost values are then not the neighbours' -- timing only, never results)."""
@@ -203,7 +204,17 @@ class NativeDistributedSw2d:
         self.plan, self.order = plan, order
         self.mesh = build_local_mesh(plan)
         self.nodes = dg.TriangleNodesProvisioner(order, self.mesh)
-        self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device, flags=sw2d.KEEP_ORDER)
+        if filter_args is not None:
+            self.nodes.buildFilter(*filter_args)
+        # fields = 4 / sources: variants C / D (tracer; Coriolis, drag, bed slope), sources as a function
+        # (x, y) -> dict(zx=, zy=, f=, CD=) of the rank-local coordinates
+        if fields == 4 or sources is not None:
+            ctx = self.nodes.dgContext()
+            src = sources(ctx.x, ctx.y) if callable(sources) else (sources or {"f": 0.0, "CD": 0.0})
+            self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device, flags=sw2d.KEEP_ORDER, fields=fields,
+                                          sources=src)
+        else:
+            self.solver = sw2d.Sw2dSolver(nodes=self.nodes, g=g, device=device, flags=sw2d.KEEP_ORDER)
         self.Np = self.solver.Np
         send = np.ascontiguousarray(plan.send_local, dtype=np.int32)
         check(lib.bdg_sw2d_set_partition(self.solver._h, plan.num_interior, plan.num_owned, ptr(send), send.size))
@@ -277,6 +288,27 @@ class NativeDistributedSw2d:
     def lserk4_stages(self, dt, nstages):
         self._check(self._lib.bdg_sw2d_lserk4_stages_exchanged(self.solver._h, float(dt), int(nstages)))
 
+    def step_rk2(self, dt, nsteps=1, filter=True):
+        """Midpoint RK2 (+ filter) of the sw2d drivers, ghosts refreshed before each of the two evaluations."""
+        self._check(self._lib.bdg_sw2d_step_rk2_exchanged(self.solver._h, float(dt), int(nsteps), int(bool(filter))))
+
+    def step_ssprk2(self, dt, nsteps=1, filter=False, sponge=0.0):
+        """Heun + sponge of the variant-B driver; with variant B enabled every evaluation also reduces the global
+        Lax-Friedrichs speed over all ranks."""
+        self._check(self._lib.bdg_sw2d_step_ssprk2_exchanged(self.solver._h, float(dt), int(nsteps), int(bool(filter)),
+                                                             float(sponge)))
+
+    def enable_variant_b(self, fields_fn, **kwargs):
+        """Variant B on this rank's part: fields_fn(x, y) -> H of the rank-local nodes (owned and ghost elements);
+        bed slopes from this rank's operators, open boundary = this rank's BCmap[2] (owned elements keep the global
+        mesh's tags). kwargs: CD, f, tide*, as Sw2dSolver.enableVariantB."""
+        ctx = self.nodes.dgContext()
+        H = fields_fn(ctx.x, ctx.y)
+        Hx, Hy = self.nodes.bedSlopes(H)
+        mapO = np.array(ctx.BCmap.get(2, []), dtype=np.int32)
+        self.solver.enableVariantB(H, Hx, Hy, mapO=mapO, **kwargs)
+        return H
+
     def allreduce_max(self, value):
         out = self._c_double()
         self._check(self._lib.bdg_sw2d_allreduce_max(self.solver._h, float(value), self._byref(out)))
@@ -301,9 +333,9 @@ class NativeDistributedSw2d:
         return float((w @ h * ctx.J[0, :n]).sum())
 
     def owned_state(self):
-        h, hu, hv = self.solver.getState()
+        q = self.solver.getState4() if self.solver.fields == 4 else self.solver.getState()
         n = self.plan.num_owned
-        return self.plan.own_global, h[:, :n], hu[:, :n], hv[:, :n]
+        return (self.plan.own_global,) + tuple(a[:, :n] for a in q)
 
 
 class DistributedSw2d:

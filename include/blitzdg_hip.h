@@ -344,6 +344,15 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
  * reads the received records directly, their initial values. Owned columns are exact. The next
  * exchanged stage refreshes the ghosts before it reads them. */
 int bdg_sw2d_lserk4_stages_exchanged(bdg_sw2d* s, double dt, int num_stages);
+/* The drivers' two-evaluation schemes in a partitioned run (bdg_sw2d_step_rk2 / bdg_sw2d_step_ssprk2 with an
+ * exchange in front of EACH evaluation, of the state that evaluation reads): midpoint RK2 + filter of the sw2d.py /
+ * sw2d-simple drivers (three or four fields, sources) and Heun + sponge of the variant-B driver. With variant B
+ * enabled every evaluation -- here and in bdg_sw2d_lserk4_stages_exchanged -- also reduces the one global
+ * Lax-Friedrichs speed (reference src/sw2d/main.cpp:414) over all ranks: a speed pass over the owned elements and
+ * one 8-byte ncclAllReduce(max) on the solver's stream; these paths are not overlapped with computation, because
+ * no element of an evaluation can start before the speed is known. Results equal the single-domain run bit for bit. */
+int bdg_sw2d_step_rk2_exchanged(bdg_sw2d* s, double dt, int num_steps, int filter);
+int bdg_sw2d_step_ssprk2_exchanged(bdg_sw2d* s, double dt, int num_steps, int filter, double sponge_coeff);
 /* In-process alternative to RCCL: all parts of the split are handles of THIS process (one per GPU
  * of the node, or several on one GPU). bdg_sw2d_local_peers takes the same neighbour tables as
  * bdg_sw2d_comm_init; bdg_sw2d_group_lserk4_stages then advances parts[0..n) (parts[r] = rank r)

@@ -140,8 +140,10 @@ def build_sponge_coeff(t, mapO, strength, radius):
     return out
 
 
-def sw2d_rhs_b(h, hu, hv, H, Hx, Hy, g, f, CD, time, t, mapO=(), global_lf=True, tide=None):
-    """main.cpp:279-484. t: tables as for sw2d_rhs4; mapO: open-boundary face nodes (BCmap[2])."""
+def sw2d_rhs_b(h, hu, hv, H, Hx, Hy, g, f, CD, time, t, mapO=(), global_lf=True, tide=None, owned=None, reduce_speed=None):
+    """main.cpp:279-484. t: tables as for sw2d_rhs4; mapO: open-boundary face nodes (BCmap[2]).
+    Partitioned runs (tests): owned = number of owned elements of a rank-local mesh (the ghost elements behind them
+    take no part in the speed maximum), reduce_speed = the all-rank maximum of this rank's value."""
     Nfp = t["nx"].shape[0] // 3
     K = t["rx"].shape[1]
     vM, vP = np.asarray(t["vmapM"]), np.asarray(t["vmapP"])
@@ -179,7 +181,8 @@ def sw2d_rhs_b(h, hu, hv, H, Hx, Hy, g, f, CD, time, t, mapO=(), global_lf=True,
     F, G = (hu, F2, G2), (hv, G2, G3)
     spd = np.maximum(np.sqrt(uM * uM + vMv * vMv) + np.sqrt(g * hM), np.sqrt(uP * uP + vPv * vPv) + np.sqrt(g * hP))
     if global_lf:
-        lam = np.full_like(spd, spd.max())                            # :414
+        top = spd.max() if owned is None else spd[:3 * Nfp * owned].max()
+        lam = np.full_like(spd, top if reduce_speed is None else reduce_speed(top))   # :414
     else:
         lam = np.repeat(spd.reshape(3 * K, Nfp).max(axis=1), Nfp)     # variants A/D: per-face maximum
     corr = 0.5 * g * hM * hM - 0.5 * g * hMstar * hMstar              # :420-421, identically zero

@@ -271,6 +271,141 @@ def test_native_multi_process_path_matches_single_domain(tmp_path, world, order,
     assert (seen == 1).all()
 
 
+# ---- variants B and D partitioned: one process per rank, the library's own communicator; variant B's global speed is
+# ---- one ncclAllReduce(max) per RHS evaluation on the solver's stream
+
+def _open_left_edge(mesh):
+    verts = np.asarray(mesh.vertices).reshape(-1, 3)
+    etov = np.asarray(mesh.elements).reshape(-1, 3)
+    bc = np.asarray(mesh.bcType).reshape(-1, 3).copy()
+    xmin = verts[:, 0].min()
+    for f, (a, b) in enumerate(((0, 1), (1, 2), (2, 0))):
+        left = (np.abs(verts[etov[:, a], 0] - xmin) < 1e-12) & (np.abs(verts[etov[:, b], 0] - xmin) < 1e-12)
+        bc[left & (bc[:, f] == 3), f] = 2
+    mesh.setBCType(bc)
+
+
+def _bed(x, y):
+    return 12.0 + 1.5 * x - 0.8 * y * y + 0.3 * np.sin(3 * x) * np.cos(2 * y)
+
+
+def _b_state(x, y):
+    return _bed(x, y) + 0.4 * np.exp(-6 * x * x - 6 * y * y), 0.8 * np.sin(3 * x + 1) * np.cos(2 * y), 0.8 * np.cos(2 * x - y)
+
+
+def _d_state(x, y):
+    h, hu, hv = _fields(x, y)
+    return h, hu, hv, h * (1.0 + 0.3 * np.sin(2 * x) * np.cos(3 * y))
+
+
+def _d_sources(x, y):
+    return {"zx": -0.5 + 0 * x, "zy": 0.5 * y, "f": 1e-1 * (1.0 + 0.5 * y), "CD": 2.5e-2}
+
+
+B_KW = dict(CD=2.5e-3, f=1.0070e-4)
+B_TIME = 0.37 * 3600 * 12.42
+VARIANT_MESH = (26, 18)
+
+
+def _variant_worker(rank, world, port, env, out_dir, variant, order):
+    import faulthandler
+    faulthandler.enable()
+    sys.path.insert(0, ROOT)
+    os.environ.update(env)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    import blitzdg_amd.pyblitzdg as dg
+    from blitzdg_amd.halo import NativeDistributedSw2d, build_plan
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*VARIANT_MESH)
+    if variant == "B":
+        _open_left_edge(mesh)
+    mesh.partitionMesh(world)
+    plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, rank, world, bctype=mesh.bcType)
+    del mesh
+    if variant == "B":
+        d = NativeDistributedSw2d(plan, order, device=0)
+    else:
+        d = NativeDistributedSw2d(plan, order, device=0, filter_args=(0.9 * order, order), fields=4, sources=_d_sources)
+    try:
+        ctx = d.nodes.dgContext()
+        if variant == "B":
+            d.enable_variant_b(_bed, **B_KW)
+            d.solver.time = B_TIME
+            d.solver.setState(*_b_state(ctx.x, ctx.y))
+            dt = 0.5 * d.compute_dt(0.25)
+            d.step_ssprk2(dt, 2, sponge=3.0)
+            d.lserk4_stages(dt, 7)                 # LSERK4 with the all-reduced speed too
+            d.step_ssprk2(dt, 1)
+        else:
+            d.solver.setState4(*_d_state(ctx.x, ctx.y))
+            dt = 0.5 * d.compute_dt(0.4)
+            d.step_rk2(dt, 3, filter=True)
+            d.lserk4_stages(dt, 6)                 # the overlapped two-chain schedule with four fields
+        d.barrier()
+        out = d.owned_state()
+        np.savez(os.path.join(out_dir, f"{variant}{rank}.npz"), ids=out[0], dt=dt, **{f"q{i}": a for i, a in enumerate(out[1:])},
+                 **d.halo_counts())
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("variant,world,order", [("B", 2, 4), ("B", 3, 6), ("D", 2, 3), ("D", 3, 6)])
+def test_variants_b_and_d_partitioned_match_single_domain(tmp_path, variant, world, order, mock_rccl, monkeypatch):
+    """Variant B (star states, tide boundary, ONE global Lax-Friedrichs speed = an 8-byte all-reduce per evaluation)
+    under Heun + sponge and LSERK4, and variant D (tracer, Coriolis array, drag, bed slope, filter) under midpoint RK2
+    and the overlapped LSERK4 schedule, on 2 and 3 rank processes through the stand-in transport: owned states equal
+    the single-domain run bit for bit (unrolled kernels at N <= 4, matrix-core kernels at N = 6)."""
+    import torch.multiprocessing as mp
+
+    import blitzdg_amd.pyblitzdg as dg
+    from blitzdg_amd import sw2d
+    # single-domain reference with the separate speed pass (the same reduction kernel the ranks run before their
+    # all-reduce; the unrolled kernel's fused next-evaluation speed agrees with it to round-off only)
+    monkeypatch.setenv("BDG_SW2D_SPEED_PASS", "1")
+    mp.start_processes(_variant_worker, args=(world, _free_port(), mock_rccl, str(tmp_path), variant, order), nprocs=world,
+                       join=True, start_method="spawn")
+    parts = [np.load(tmp_path / f"{variant}{r}.npz") for r in range(world)]
+    dt = float(parts[0]["dt"])
+    assert all(float(p["dt"]) == dt for p in parts)
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*VARIANT_MESH)
+    if variant == "B":
+        _open_left_edge(mesh)
+        nodes = dg.TriangleNodesProvisioner(order, mesh)
+        ctx = nodes.dgContext()
+        s = sw2d.Sw2dSolver(nodes=nodes, flags=sw2d.KEEP_ORDER)
+        H = _bed(ctx.x, ctx.y)
+        Hx, Hy = nodes.bedSlopes(H)
+        s.enableVariantB(H, Hx, Hy, mapO=np.array(ctx.BCmap.get(2, []), dtype=np.int32), **B_KW)
+        s.time = B_TIME
+        s.setState(*_b_state(ctx.x, ctx.y))
+        assert 0.5 * s.computeDt(0.25)[0] == dt
+        s.stepSSPRK2(dt, 2, sponge=3.0)
+        s.lserk4Stages(dt, 7)
+        s.stepSSPRK2(dt, 1)
+        ref = s.getState()
+    else:
+        nodes = dg.TriangleNodesProvisioner(order, mesh)
+        nodes.buildFilter(0.9 * order, order)
+        ctx = nodes.dgContext()
+        s = sw2d.Sw2dSolver(nodes=nodes, flags=sw2d.KEEP_ORDER, fields=4, sources=_d_sources(ctx.x, ctx.y))
+        s.setState4(*_d_state(ctx.x, ctx.y))
+        assert 0.5 * s.computeDt(0.4)[0] == dt
+        s.stepRK2(dt, 3, filter=True)
+        s.lserk4Stages(dt, 6)
+        ref = s.getState4()
+    seen = np.zeros(mesh.numElements, dtype=int)
+    for p in parts:
+        ids = p["ids"]
+        seen[ids] += 1
+        assert int(p["ghost"]) > 0
+        for i, full in enumerate(ref):
+            assert np.array_equal(p[f"q{i}"], full[:, ids]), f"field {i} differs on a rank"
+    assert (seen == 1).all()
+    assert np.abs(ref[1] - (_b_state(ctx.x, ctx.y) if variant == "B" else _d_state(ctx.x, ctx.y))[1]).max() > 1e-6
+
+
 def test_bench_two_ranks_through_the_mock_transport(mock_rccl):
     """bench.py as the driver launches it for N = 2 (two processes, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*),
     both on this GPU through the stand-in transport: rank 0 prints the one JSON line, rank 1 nothing."""

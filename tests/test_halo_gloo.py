@@ -120,6 +120,126 @@ def test_partitioned_lserk4_equals_single_domain(tmp_path, world, mesh_args, ord
     assert (seen == 1).all()  # every element owned exactly once
 
 
+def _open_left_edge(mesh):
+    """Faces on x = xmin re-tagged Out (2), as the variant-B driver does before its second buildBCHash."""
+    verts = np.asarray(mesh.vertices).reshape(-1, 3)
+    etov = np.asarray(mesh.elements).reshape(-1, 3)
+    bc = np.asarray(mesh.bcType).reshape(-1, 3).copy()
+    xmin = verts[:, 0].min()
+    for f, (a, b) in enumerate(((0, 1), (1, 2), (2, 0))):
+        left = (np.abs(verts[etov[:, a], 0] - xmin) < 1e-12) & (np.abs(verts[etov[:, b], 0] - xmin) < 1e-12)
+        bc[left & (bc[:, f] == 3), f] = 2
+    mesh.setBCType(bc)
+
+
+def _bed(x, y):
+    return 12.0 + 1.5 * x - 0.8 * y * y + 0.3 * np.sin(3 * x) * np.cos(2 * y)
+
+
+def _b_state(x, y):
+    return _bed(x, y) + 0.4 * np.exp(-6 * x * x - 6 * y * y), 0.8 * np.sin(3 * x + 1) * np.cos(2 * y), 0.8 * np.cos(2 * x - y)
+
+
+B_PHYS = dict(g=9.81, f=1.0070e-4, CD=2.5e-3, time=0.37 * 3600 * 12.42)
+
+
+def _b_worker(rank, world, port, mesh_args, order, nsteps, dt, out_dir):
+    """Variant B on a partition: per RHS evaluation the ghosts of the evaluated state are exchanged and the one global
+    Lax-Friedrichs speed is the all-reduced maximum of the ranks' owned-element maxima (gloo all_reduce MAX)."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    import blitzdg_amd.pyblitzdg as dg
+    from blitzdg_amd.halo import build_local_mesh, build_plan, exchange_ops
+    from oracle import oracle_np as onp
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        mesh = dg.MeshManager()
+        mesh.buildBoxMesh(*mesh_args[:2], shuffleSeed=mesh_args[2])
+        _open_left_edge(mesh)
+        mesh.partitionMesh(world)
+        plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, rank, world,
+                          bctype=mesh.bcType)
+        nodes = dg.TriangleNodesProvisioner(order, build_local_mesh(plan))
+        ctx = nodes.dgContext()
+        t = _tables(nodes)
+        mapO = np.array(ctx.BCmap.get(2, []), dtype=np.int32)
+        H = _bed(t["x"], t["y"])
+        Hx, Hy = nodes.bedSlopes(H)
+        q = list(_b_state(t["x"], t["y"]))
+        Np, n_own, n_halo = q[0].shape[0], plan.num_owned, plan.num_halo
+
+        def refresh(state):
+            for a in state:
+                a[:, n_own:] = np.nan
+            full = np.concatenate(state, axis=0)
+            sendbuf = torch.from_numpy(np.ascontiguousarray(full[:, plan.send_local].T))
+            recvbuf = torch.zeros((max(n_halo, 1), 3 * Np), dtype=torch.float64)
+            for w in dist.batch_isend_irecv(exchange_ops(plan, sendbuf, recvbuf, dist)):
+                w.wait()
+            ghosts = recvbuf.numpy()[:n_halo].T
+            for c in range(3):
+                state[c][:, n_own:] = ghosts[c * Np:(c + 1) * Np]
+
+        def allmax(v):
+            tv = torch.tensor([v], dtype=torch.float64)
+            dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+            return float(tv.item())
+
+        def rhs(state):
+            refresh(state)
+            return onp.sw2d_rhs_b(*state, H, Hx, Hy, B_PHYS["g"], B_PHYS["f"], B_PHYS["CD"], B_PHYS["time"], t, mapO,
+                                  owned=n_own, reduce_speed=allmax)
+        for _ in range(nsteps):                                          # Heun, both evaluations at the old time level
+            r = rhs(q)
+            q1 = [a + dt * b for a, b in zip(q, r)]
+            r = rhs(q1)
+            q = [0.5 * (a + a1 + dt * b) for a, a1, b in zip(q, q1, r)]
+        np.savez(os.path.join(out_dir, f"rankB{rank}.npz"), ids=plan.own_global, h=q[0][:, :n_own], hu=q[1][:, :n_own],
+                 hv=q[2][:, :n_own], nout=mapO.size)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mesh_args,order", [(2, (6, 5, 0), 3), (3, (7, 6, 31), 2)])
+def test_partitioned_variant_b_with_all_reduced_speed_equals_single_domain(tmp_path, world, mesh_args, order):
+    """Variant B's ONE global speed (reference src/sw2d/main.cpp:414) in a partitioned run = max over ranks of the
+    owned-element maxima: Heun steps on 2 and 3 ranks equal the single-domain restatement bit for bit."""
+    import torch.multiprocessing as mp
+
+    import blitzdg_amd.pyblitzdg as dg
+    from oracle import oracle_np as onp
+
+    nsteps, dt = 3, 1e-3
+    mp.start_processes(_b_worker, args=(world, _free_port(), mesh_args, order, nsteps, dt, str(tmp_path)), nprocs=world,
+                       join=True, start_method="spawn")
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*mesh_args[:2], shuffleSeed=mesh_args[2])
+    _open_left_edge(mesh)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    ctx = nodes.dgContext()
+    t = _tables(nodes)
+    mapO = np.array(ctx.BCmap.get(2, []), dtype=np.int32)
+    H = _bed(t["x"], t["y"])
+    Hx, Hy = nodes.bedSlopes(H)
+    q = list(_b_state(t["x"], t["y"]))
+    for _ in range(nsteps):
+        r = onp.sw2d_rhs_b(*q, H, Hx, Hy, B_PHYS["g"], B_PHYS["f"], B_PHYS["CD"], B_PHYS["time"], t, mapO)
+        q1 = [a + dt * b for a, b in zip(q, r)]
+        r = onp.sw2d_rhs_b(*q1, H, Hx, Hy, B_PHYS["g"], B_PHYS["f"], B_PHYS["CD"], B_PHYS["time"], t, mapO)
+        q = [0.5 * (a + a1 + dt * b) for a, a1, b in zip(q, q1, r)]
+    seen, nout = np.zeros(mesh.numElements, dtype=int), 0
+    for r in range(world):
+        d = np.load(tmp_path / f"rankB{r}.npz")
+        seen[d["ids"]] += 1
+        nout += int(d["nout"])
+        for name, full in zip(("h", "hu", "hv"), q):
+            assert np.array_equal(d[name], full[:, d["ids"]]), name
+    assert (seen == 1).all() and nout >= mapO.size and mapO.size > 0
+
+
 def test_plan_is_consistent_between_ranks():
     """Send lists and ghost lists of every pair of ranks name the same elements in the same
     order; interior elements have no remote neighbour."""
