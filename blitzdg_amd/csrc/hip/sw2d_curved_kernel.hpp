@@ -33,6 +33,15 @@ typedef double cmfma_t __attribute__((ext_vector_type(4)));
 
 enum { CMODE_RHS = 0, CMODE_LSERK = 1, CMODE_COMBINE = 2 };
 
+// Zero accumulator the compiler cannot see through (a literal 0 as the C operand of a chain's first matrix instruction lets
+// hipcc allocate a destination that overlaps the A operand, which the multi-pass instruction is still reading: see
+// mfma_zero in sw2d_mfma3_kernel.hpp and tests/test_isa_hazards.py).
+__device__ __forceinline__ cmfma_t cmfma_zero() {
+    cmfma_t z{0.0, 0.0, 0.0, 0.0};
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
 struct CurvedParams {
     const double* qin;    // 4 planes of Np*ld: h, hu, hv, hN
     const double* qbase;  // CMODE_COMBINE
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void sw2d_curved_gauss_kernel(const CurvedPara
         for (int gb = 0; gb < ngb; ++gb) {
             cmfma_t gv[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) gv[c] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < 4; ++c) gv[c] = cmfma_zero();
 #pragma unroll
             for (int t = 0; t < KV; ++t) {
                 const double a = sOps[(gb * KV + t) * 64 + lane];
@@ -260,13 +269,13 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < MT; ++r) acc[c][r] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < MT; ++r) acc[c][r] = cmfma_zero();
 
         // ---- volume term, 16 cubature points at a time
         for (int rb = 0; rb < ncb; ++rb) {
             cmfma_t cv[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) cv[c] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < 4; ++c) cv[c] = cmfma_zero();
 #pragma unroll
             for (int t = 0; t < KV; ++t) {
                 const double a = A(rb * KV + t);
@@ -371,7 +380,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int r = 0; r < MT; ++r) out[c][r] = cmfma_t{0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < MT; ++r) out[c][r] = cmfma_zero();
         double S2[KV], S3[KV];
 #pragma unroll
         for (int t = 0; t < KV; ++t) {

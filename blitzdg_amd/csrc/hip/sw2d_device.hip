@@ -486,6 +486,9 @@ struct bdg_sw2d {
     // the matrix cores at every size)
     static constexpr int kSmallLaunch[6] = {0, 4000, 10000, 100000, 160000, 0};
     bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
+    // resident-workgroup kernels, interior launch of a partitioned run: CUs left to the boundary kernel (a strip of a few
+    // hundred elements = 4..8 four-wave workgroups); N=8, 8-way rehearsal: 0.087 -> see profiles/r02_rehearsal.txt
+    static constexpr int kInteriorGridCap = 244;
 
     void launchRhs(const double* qin, double* out, bool filter) {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
@@ -500,7 +503,10 @@ struct bdg_sw2d {
     void launchLserkStage(int part = 2, hipStream_t on = nullptr, bool advance = true) {
         const int s = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
         bdg_dev::StageParams p = baseParams();
-        if (part == 0) p.kend = numInterior;
+        if (part == 0) {
+            p.kend = numInterior;
+            p.gridCap = kInteriorGridCap; // the boundary kernel runs beside this launch (exchange stream)
+        }
         if (part == 1) p.kbegin = numInterior;
         p.qin = qcur;
         p.qout = qalt;
@@ -605,8 +611,9 @@ struct bdg_sw2d {
         p.haloOwned = numOwned; p.haloRows = nf * Np;
         if (N >= 5) { // the kernel family the interior (and a single-domain run) uses: bit-identical arithmetic
             p.opsAffine = opsMfma2.p;
-            hipCheck(affineVariant == 6 ? kt->stageMfma2Halo(p, on) : kt->stageMfma3Halo(p, on),
-                     "sw2d boundary stage kernel <LSERK, halo>");
+            static const char* haloVariant = std::getenv("BDG_SW2D_HALO_VARIANT"); // A/B switch: "6" = two-waves schedule
+            const bool two = affineVariant == 6 || (haloVariant && haloVariant[0] == '6');
+            hipCheck(two ? kt->stageMfma2Halo(p, on) : kt->stageMfma3Halo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
         } else {
             p.opsAffine = opsMfma.p;
             hipCheck(kt->stageMfmaHalo(p, on), "sw2d boundary stage kernel <LSERK, halo>");

@@ -79,6 +79,10 @@ struct StageParams {
     const int* haloSendOf;  // 3 send-record indices per element of [kbegin, kend), -1 = none
     int haloOwned;          // first ghost slot
     int haloRows;           // doubles per record = fields * Np
+    // Launches with one resident workgroup per CU for their whole duration (sw2d_stage_mfma3_kernel): at most this many
+    // workgroups (0: one per CU). Interior launches of a partitioned run leave a few CUs to the partition-boundary
+    // kernel on the exchange stream, which could not start beside 256 LDS-filling workgroups otherwise.
+    int gridCap;
 };
 
 // Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):

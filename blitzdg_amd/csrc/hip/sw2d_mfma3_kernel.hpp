@@ -23,8 +23,10 @@ namespace bdg_dev {
 
 // Row accesses go through buffer instructions: a wave-uniform descriptor per plane, ONE per-lane byte offset per tile
 // ((q ld + k) 8: lane (q, j) always touches rows 4 t + q of its element k) and the row group 4 t as a scalar offset.
-// No per-load 64-bit address lives in vector registers (72 row loads in flight would need 144 of them), and rows
-// beyond the plane (the padding nodes m >= Np of the last k-step) are bounds-checked away by the hardware.
+// No per-load 64-bit address lives in vector registers (72 row loads in flight would need 144 of them). The hardware's
+// range check of a raw buffer looks at the VECTOR offset only (the scalar offset is added after it), so the padding
+// nodes m >= Np of the last k-step are taken out by giving those lanes an out-of-range vector offset (row_voffset):
+// their loads return 0 and their stores are dropped, and nothing beyond a plane is ever touched.
 typedef unsigned int bdg_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
@@ -37,6 +39,28 @@ __device__ __forceinline__ int bld_i32(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 }
 __device__ __forceinline__ void bst_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bdg_u32x2, v), r, voff, soff, 0);
+}
+
+// Zero accumulator the compiler cannot see through. With a literal 0 as the C operand of the first matrix instruction of
+// a chain, hipcc is free to allocate a fresh destination for it, and under register pressure it has picked one that
+// overlaps the A operand (v_mfma_f64_16x16x4_f64 a[16:23], a[22:23], v[..], 0 in the strip kernel below at N = 8). The
+// multi-pass instruction reads its A operand while it writes its destination: sixteen result rows came out wrong. An
+// accumulator that is already live is updated in place (dst = C) and cannot overlap the A / B operands.
+// tests/test_isa_hazards.py scans the generated code for such overlaps.
+__device__ __forceinline__ mfma_acc_t mfma_zero() {
+    mfma_acc_t z{0.0, 0.0, 0.0, 0.0};
+    asm volatile("" : "+v"(z));
+    return z;
+}
+
+// Vector offset of row 4 t + q for the lane whose in-range offset is v8: lanes whose row is a padding row get an offset
+// beyond every plane (planes are < 4 GiB, checked at creation).
+template <int Np, int KV>
+__device__ __forceinline__ unsigned row_voffset(int t, unsigned q, unsigned v8) {
+    if constexpr (Np % 4 != 0) {
+        if (t == KV - 1) return (4 * (KV - 1) + static_cast<int>(q) < Np) ? v8 : 0xfffffff8u;
+    }
+    return v8;
 }
 
 template <int N>
@@ -101,14 +125,15 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
     auto loadStateRow = [&](unsigned kk, int t, double (&qs)[3][KV]) {
         const unsigned v8 = (q * static_cast<unsigned>(ld) + kk) * 8u;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) qs[c][t] = bld_f64(rq[c], v8, static_cast<unsigned>(4 * t) * ld8); // 0 beyond the plane
+        for (int c = 0; c < 3; ++c) qs[c][t] = bld_f64(rq[c], row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8); // padding rows: 0
     };
     auto loadIndices = [&](unsigned kk, int (&ix)[3][KF]) {
         const unsigned v4 = (q * static_cast<unsigned>(ld) + kk) * 4u;
 #pragma unroll
         for (int f = 0; f < 3; ++f)
 #pragma unroll
-            for (int tf = 0; tf < KF; ++tf) ix[f][tf] = bld_i32(ridx, v4, static_cast<unsigned>(f * Nfp + 4 * tf) * ld4);
+            for (int tf = 0; tf < KF; ++tf) // lanes beyond the face's nodes: out-of-range offset, value 0
+                ix[f][tf] = bld_i32(ridx, (4 * tf + static_cast<int>(q) < Nfp) ? v4 : 0xfffffffcu, static_cast<unsigned>(f * Nfp + 4 * tf) * ld4);
     };
     auto loadGeometry = [&](unsigned kk, double (&gg)[13]) {
 #pragma unroll
@@ -172,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int r = 0; r < MT; ++r) acc[c][r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
+            for (int r = 0; r < MT; ++r) acc[c][r] = mfma_zero(); // not a literal 0: see mfma_zero
 
         const double rx = geo[0], sx = geo[1], ry = geo[2], sy = geo[3];
         // volume term, software pipelined by hand: the six operands of k-step t + 1 are formed (vector ALU) in the same
@@ -272,7 +297,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
-                for (int t = 0; t < KV; ++t) oldv[c][t] = bld_f64(rold[c], v8, static_cast<unsigned>(4 * t) * ld8);
+                for (int t = 0; t < KV; ++t) oldv[c][t] = bld_f64(rold[c], row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
         }
         loadGeometry(kN, geoN);
         __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- stage update / output: node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3); stores of the
-        //      padding rows fall outside the plane and are dropped by the bounds check, padding lanes store nothing
+        //      padding rows carry an out-of-range vector offset (row_voffset) and are dropped, padding lanes store nothing
         if (live) {
             int sendRec[3] = {-1, -1, -1};
             if constexpr (HALO) {
@@ -310,12 +335,12 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                     const double R = acc[c][t >> 2][t & 3];
                     const double own = m < Np ? sOps[sBase + (c * Np + m) * 16] : 0.0;
                     if constexpr (MODE == MODE_RHS) {
-                        bst_f64(rout[c], v8, soff, R);
+                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, R);
                     } else if constexpr (MODE == MODE_LSERK) {
                         const double n1 = p.ca * oldv[c][t] + p.cc * R;
                         const double qn = own + p.cb * n1;
-                        bst_f64(rres[c], v8, soff, n1);
-                        bst_f64(rout[c], v8, soff, qn);
+                        bst_f64(rres[c], row_voffset<Np, KV>(t, q, v8), soff, n1);
+                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, qn);
                         if constexpr (HALO) {
                             if (m < Np) {
 #pragma unroll
@@ -326,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                         }
                     } else {
                         const double val = p.ca * oldv[c][t] + p.cb * own + p.cc * R;
-                        bst_f64(rout[c], v8, soff, c == 0 ? val : sponge_relax(val, p.sponge));
+                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, c == 0 ? val : sponge_relax(val, p.sponge));
                     }
                 }
         }
@@ -347,6 +372,188 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                 fidx[f][tf] = fidxN[f][tf];
                 hP[f][tf] = hPN[f][tf]; huP[f][tf] = huPN[f][tf]; hvP[f][tf] = hvPN[f][tf];
             }
+    }
+}
+
+} // namespace bdg_dev
+
+namespace bdg_dev {
+
+// ---------------------------------------------------------------------------------------------
+// Partition-boundary strip of an exchanged LSERK4 stage (a few hundred elements between the received ghosts and the
+// records to send): latency, not throughput, is what counts -- the strip kernel sits on the exchange chain
+// (receive -> strip -> send) that every stage has to get through, and a tile's instruction stream on ONE wave takes
+// 40-60 us (N=8: profiles/r02_rehearsal_n8.txt) whatever the schedule. Here a tile of 16 elements is shared by the
+// three waves of a workgroup, one conserved field each: every wave forms the operands of its own field and issues a
+// third of the matrix instructions, in the same order as sw2d_stage_mfma3_kernel (volume k-steps, then faces), and
+// does its own field's stage update, halo staging included (ghost traces from the received records, new state to the
+// send records). The wave speed of a face needs all three fields, so traces are loaded by all three waves (L1 hits).
+template <int N>
+__global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StageParams p) {
+    using E = Elem<N>;
+    using O = MfmaOps2<N>;
+    constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
+
+    extern __shared__ double sOps[];
+    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    const int c = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)); // field of this wave
+    const unsigned ntiles = (static_cast<unsigned>(p.kend - p.kbegin) + 15u) / 16u;
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
+    const double g = p.g, halfg = 0.5 * p.g;
+    const unsigned kLast = static_cast<unsigned>(p.kend) - 1u;
+    const unsigned planeBytes = static_cast<unsigned>(plane * 8), ld8 = static_cast<unsigned>(ld) * 8u, ld4 = static_cast<unsigned>(ld) * 4u;
+    __amdgpu_buffer_rsrc_t rq[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rq[i] = plane_rsrc(p.qin + i * plane, planeBytes);
+    const __amdgpu_buffer_rsrc_t rres = plane_rsrc(p.res + c * plane, planeBytes), rout = plane_rsrc(p.qout + c * plane, planeBytes);
+    const __amdgpu_buffer_rsrc_t rgeo = plane_rsrc(p.ageo, 13u * ld8), ridx = plane_rsrc(p.vmapP, 3u * Nfp * ld4);
+    const __amdgpu_buffer_rsrc_t rrecv = plane_rsrc(p.haloRecv, 0xffffffffu);
+
+    for (unsigned tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const unsigned kTrue = static_cast<unsigned>(p.kbegin) + tile * 16u + j;
+        const bool live = kTrue <= kLast;
+        const unsigned k = live ? kTrue : kLast;
+        const unsigned k8 = k * 8u, v8 = (q * static_cast<unsigned>(ld) + k) * 8u, v4 = (q * static_cast<unsigned>(ld) + k) * 4u;
+
+        // ---- everything this tile reads, requested up front (the gathers follow their indices)
+        int fidx[3][KF];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf)
+                fidx[f][tf] = bld_i32(ridx, (4 * tf + static_cast<int>(q) < Nfp) ? v4 : 0xfffffffcu, static_cast<unsigned>(f * Nfp + 4 * tf) * ld4);
+        double qB[3][KV], geo[13], oldv[KV];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int t = 0; t < KV; ++t) qB[i][t] = bld_f64(rq[i], row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) geo[i] = bld_f64(rgeo, k8, static_cast<unsigned>(i) * ld8);
+#pragma unroll
+        for (int t = 0; t < KV; ++t) oldv[t] = bld_f64(rres, row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
+        double hM[3][KF], huM[3][KF], hvM[3][KF], hP[3][KF], huP[3][KF], hvP[3][KF];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const int n = 4 * tf + static_cast<int>(q);
+                const int m = n < Nfp ? fmask_rt<N>(f, n) : 0;
+                const unsigned m8 = (static_cast<unsigned>(m) * static_cast<unsigned>(ld) + k) * 8u;
+                hM[f][tf] = bld_f64(rq[0], m8, 0u);
+                huM[f][tf] = bld_f64(rq[1], m8, 0u);
+                hvM[f][tf] = bld_f64(rq[2], m8, 0u);
+                const int id = n < Nfp ? fidx[f][tf] : 0;
+                const unsigned idp = static_cast<unsigned>(id < 0 ? -(id + 1) : id), o8 = idp * 8u;
+                const unsigned row = idp / static_cast<unsigned>(ld), slot = idp - row * static_cast<unsigned>(ld);
+                if (slot >= static_cast<unsigned>(p.haloOwned)) { // the neighbour's record as it arrived: [field][node]
+                    const unsigned rec8 = ((slot - static_cast<unsigned>(p.haloOwned)) * static_cast<unsigned>(p.haloRows) + row) * 8u;
+                    hP[f][tf] = bld_f64(rrecv, rec8, 0u);
+                    huP[f][tf] = bld_f64(rrecv, rec8, static_cast<unsigned>(Np) * 8u);
+                    hvP[f][tf] = bld_f64(rrecv, rec8, static_cast<unsigned>(2 * Np) * 8u);
+                } else {
+                    hP[f][tf] = bld_f64(rq[0], o8, 0u);
+                    huP[f][tf] = bld_f64(rq[1], o8, 0u);
+                    hvP[f][tf] = bld_f64(rq[2], o8, 0u);
+                }
+            }
+        int sendRec[3] = {-1, -1, -1};
+        if (live) {
+            const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
+            sendRec[0] = p.haloSendOf[b3];
+            sendRec[1] = p.haloSendOf[b3 + 1];
+            sendRec[2] = p.haloSendOf[b3 + 2];
+        }
+
+        mfma_acc_t acc[MT];
+#pragma unroll
+        for (int r = 0; r < MT; ++r) acc[r] = mfma_zero(); // not a literal 0: see mfma_zero
+
+        // ---- volume term: the two operands of this wave's field per k-step
+        const double rx = geo[0], sx = geo[1], ry = geo[2], sy = geo[3];
+#pragma unroll
+        for (int t = 0; t < KV; ++t) {
+            const int m = 4 * t + static_cast<int>(q);
+            const bool pad = m >= Np;
+            const double h = pad ? 1.0 : qB[0][t], hu = qB[1][t], hv = qB[2][t];
+            const double r = fast_rcp(h);
+            const double u = hu * r, v = hv * r;
+            const double pr = halfg * h * h;
+            const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
+            const double w = pad ? 0.0 : -1.0;
+            const double Fc = c == 0 ? hu : (c == 1 ? F2 : G2), Gc = c == 0 ? hv : (c == 1 ? G2 : G3);
+            const double a = w * (rx * Fc + ry * Gc), b = w * (sx * Fc + sy * Gc);
+#pragma unroll
+            for (int r2 = 0; r2 < MT; ++r2) {
+                acc[r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane], a, acc[r2], 0, 0, 0);
+                acc[r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane], b, acc[r2], 0, 0, 0);
+            }
+        }
+
+        // ---- surface term
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const double nxf = geo[4 + f], nyf = geo[7 + f], hfs = 0.5 * geo[10 + f];
+            double e[KF], d[KF], lam = 0.0;
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const int n = 4 * tf + static_cast<int>(q);
+                e[tf] = d[tf] = 0.0;
+                if (n < Nfp) {
+                    const double hMv = hM[f][tf], huMv = huM[f][tf], hvMv = hvM[f][tf], hq = hP[f][tf];
+                    double huq = huP[f][tf], hvq = hvP[f][tf];
+                    if (fidx[f][tf] < 0) { // reflective wall: no normal flow
+                        const double un = huMv * nxf + hvMv * nyf;
+                        huq = huMv - 2 * nxf * un;
+                        hvq = hvMv - 2 * nyf * un;
+                    }
+                    const double rM = fast_rcp(hMv), rP = fast_rcp(hq);
+                    const double uM = huMv * rM, vM = hvMv * rM, uP = huq * rP, vP = hvq * rP;
+                    const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hMv);
+                    const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                    lam = fmax(lam, fmax(spdM, spdP));
+                    const double prM = halfg * hMv * hMv, prP = halfg * hq * hq;
+                    const double F2M = huMv * uM + prM, G2M = huMv * vM, G3M = hvMv * vM + prM;
+                    const double F2P = huq * uP + prP, G2P = huq * vP, G3P = hvq * vP + prP;
+                    const double d1 = hMv - hq, d2 = huMv - huq, d3 = hvMv - hvq;
+                    d[tf] = c == 0 ? d1 : (c == 1 ? d2 : d3);
+                    const double e1 = d2 * nxf + d3 * nyf;
+                    const double e2 = (F2M - F2P) * nxf + (G2M - G2P) * nyf;
+                    const double e3 = (G2M - G2P) * nxf + (G3M - G3P) * nyf;
+                    e[tf] = c == 0 ? e1 : (c == 1 ? e2 : e3);
+                }
+            }
+            lam = fmax(lam, __shfl_xor(lam, 16));
+            lam = fmax(lam, __shfl_xor(lam, 32));
+#pragma unroll
+            for (int tf = 0; tf < KF; ++tf) {
+                const double s = hfs * (e[tf] - lam * d[tf]);
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+                    acc[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane], s, acc[r], 0, 0, 0);
+            }
+        }
+
+        // ---- LSERK4 stage update of this wave's field, new state also to the element's send records
+        if (live) {
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const int m = 4 * t + static_cast<int>(q);
+                const unsigned soff = static_cast<unsigned>(4 * t) * ld8;
+                const double own = c == 0 ? qB[0][t] : (c == 1 ? qB[1][t] : qB[2][t]);
+                const double n1 = p.ca * oldv[t] + p.cc * acc[t >> 2][t & 3];
+                const double qn = own + p.cb * n1;
+                bst_f64(rres, row_voffset<Np, KV>(t, q, v8), soff, n1);
+                bst_f64(rout, row_voffset<Np, KV>(t, q, v8), soff, qn);
+                if (m < Np) {
+#pragma unroll
+                    for (int sr = 0; sr < 3; ++sr)
+                        if (sendRec[sr] >= 0) p.haloSend[static_cast<size_t>(sendRec[sr]) * p.haloRows + c * Np + m] = qn;
+                }
+            }
+        }
     }
 }
 

@@ -1,6 +1,7 @@
 // Instantiates the sw2d kernels for one polynomial order (-DBDG_ORDER=N).
 #include "sw2d_launch.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 #ifndef BDG_ORDER
 #error "compile with -DBDG_ORDER=<polynomial order>"
@@ -236,7 +237,8 @@ hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
-    const unsigned grid = std::min((ntiles + 3u) / 4u, 256u); // one four-wave workgroup per CU, one wave per SIMD
+    const unsigned cap = p.gridCap > 0 ? static_cast<unsigned>(p.gridCap) : 256u;
+    const unsigned grid = std::min((ntiles + 3u) / 4u, cap); // one four-wave workgroup per CU, one wave per SIMD
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }
@@ -252,6 +254,13 @@ hipError_t stageMfma3Halo(const StageParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
     }
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
+    // Strips (up to a few thousand elements): the latency form, a tile shared by three waves (one field each). Larger
+    // boundary sets: the throughput form.
+    if (ntiles <= 1024u && !std::getenv("BDG_SW2D_STRIP_THROUGHPUT")) {
+        const size_t stripLds = sizeof(double) * MfmaOps2<kN>::DOUBLES;
+        hipLaunchKernelGGL((sw2d_strip_mfma3_kernel<kN>), dim3(ntiles), dim3(192), stripLds, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kern, dim3(std::min((ntiles + 3u) / 4u, 256u)), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }

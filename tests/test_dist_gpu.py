@@ -147,6 +147,10 @@ def test_overlapped_two_chain_schedule_matches_single_domain(order, world, shape
     send records); halo_kernels=True (BDG_SW2D_HALO_KERNELS=1) keeps the separate pack / unpack kernels."""
     if halo_kernels:
         monkeypatch.setenv("BDG_SW2D_HALO_KERNELS", "1")
+    # N >= 5: the strip runs on the throughput form of the kernel the interior uses (identical arithmetic, so the comparison
+    # can be bit for bit); the default latency form of the strip kernel (one field per wave) is covered by
+    # test_strip_kernel_matches_single_domain_to_round_off
+    monkeypatch.setenv("BDG_SW2D_STRIP_THROUGHPUT", "1")
     import blitzdg_amd.pyblitzdg as dg
     from blitzdg_amd import sw2d
     from blitzdg_amd.halo import LocalGroupSw2d
@@ -169,6 +173,39 @@ def test_overlapped_two_chain_schedule_matches_single_domain(order, world, shape
         got, ref = group.gather_state(), single.getState()
         for a, b in zip(got, ref):
             assert np.array_equal(a, b)
+        assert np.abs(ref[1] - q0[1]).max() > 1e-4
+    finally:
+        group.close()
+
+
+@pytest.mark.parametrize("order,world,shape", [(5, 3, (30, 24)), (6, 4, (24, 20)), (7, 2, (16, 12)), (8, 2, (12, 10)), (8, 5, (20, 16))])
+def test_strip_kernel_matches_single_domain_to_round_off(order, world, shape):
+    """Default partition-boundary kernel at N >= 5: sw2d_strip_mfma3_kernel, a tile shared by three waves (one conserved
+    field each) with the halo staging folded in. Its operands are formed by other instruction sequences than the interior
+    kernel's (FMA contraction differs), so the assembled state agrees with the single-domain run to round-off, not bit for
+    bit: <= 1e-12 after 23 stages. (At N = 8 a first version was off by 1e-6: the compiler had placed the destination of a
+    chain's first matrix instruction over its A operand -- see mfma_zero and tests/test_isa_hazards.py.)"""
+    import blitzdg_amd.pyblitzdg as dg
+    from blitzdg_amd import sw2d
+    from blitzdg_amd.halo import LocalGroupSw2d
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*shape)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    ctx = nodes.dgContext()
+    single = sw2d.Sw2dSolver(nodes=nodes)
+    q0 = _fields(ctx.x, ctx.y)
+    single.setState(*q0)
+    dt = 0.5 * single.computeDt(0.65)[0]
+    group = LocalGroupSw2d(mesh, order, world)
+    try:
+        group.set_global_state(*q0)
+        for chunk in (1, 2, 7, 13):
+            group.lserk4_stages(dt, chunk)
+            single.lserk4Stages(dt, chunk)
+        got, ref = group.gather_state(), single.getState()
+        for a, b in zip(got, ref):
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+        assert any(not np.array_equal(a, b) for a, b in zip(got, ref))   # it IS another kernel than the interior's
         assert np.abs(ref[1] - q0[1]).max() > 1e-4
     finally:
         group.close()
@@ -228,6 +265,7 @@ def _native_worker(rank, world, port, env, out_dir, order=ORDER):
     faulthandler.enable()
     sys.path.insert(0, ROOT)
     os.environ.update(env)
+    os.environ["BDG_SW2D_STRIP_THROUGHPUT"] = "1"   # N >= 5: the strip on the interior's own kernel form (bit-for-bit comparison)
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port)})
     from blitzdg_amd.halo import NativeDistributedSw2d
