@@ -1781,12 +1781,16 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         s->commWorld = world;
         s->peers = peers;
         hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
-        // These four events only order kernels of the two streams of THIS device against each other. Default
-        // record semantics (system-scope fence) until a run between distinct GPUs has shown bit-exact parity
-        // without it; BDG_SW2D_EVENT_NOFENCE=1 drops the fence (2-3 us per stage; tests/test_dist_gpu.py
-        // compares both settings bit for bit on the loop-back RCCL path).
-        const char* nofence = std::getenv("BDG_SW2D_EVENT_NOFENCE");
-        const unsigned evFlags = hipEventDisableTiming | ((nofence && nofence[0] == '1') ? hipEventDisableSystemFence : 0u);
+        // These four events only order kernels of the two streams of THIS device against each other (a kernel's own
+        // end-of-kernel release is device-wide, and data from another GPU is made visible by the RCCL kernel that received
+        // it, on the stream that then runs the boundary kernel): the system-scope fence of a default event record is not
+        // needed and costs 2-3 us per stage (8-way rehearsal, N=4: 0.056 ms per stage without, 0.058-0.059 with).
+        // tests/test_dist_gpu.py::test_loopback_rccl_result_is_independent_of_event_flags_and_halo_staging compares both
+        // settings bit for bit through real RCCL; BDG_SW2D_EVENT_FENCE=1 (or BDG_SW2D_EVENT_NOFENCE=0) restores the fence.
+        const char* fenceOn = std::getenv("BDG_SW2D_EVENT_FENCE");
+        const char* fenceOff = std::getenv("BDG_SW2D_EVENT_NOFENCE");
+        const bool fence = (fenceOn && fenceOn[0] == '1') || (fenceOff && fenceOff[0] == '0');
+        const unsigned evFlags = hipEventDisableTiming | (fence ? 0u : hipEventDisableSystemFence);
         for (hipEvent_t* e : {&s->evA[0], &s->evA[1], &s->evB[0], &s->evB[1]})
             hipCheck(hipEventCreateWithFlags(e, evFlags), "hipEventCreate");
         const size_t rows = static_cast<size_t>(s->nf) * s->Np;

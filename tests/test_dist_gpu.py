@@ -245,6 +245,40 @@ def test_bench_loopback_rehearsal_of_an_eight_way_split():
         assert r["owned"] == 3200 and r["ghost"] > 0 and r["peers"] >= 1 and 0 < r["ms_per_stage"] < 5
 
 
+@pytest.mark.parametrize("order", [4, 6])
+def test_loopback_rccl_result_is_independent_of_event_flags_and_halo_staging(order, monkeypatch):
+    """Real RCCL (send-to-self of the true message sizes; rank 5's share of an 8-way split) through the asynchronous
+    two-chain schedule: the final state must be bit-identical whether the four cross-stream events carry the
+    system-scope fence (default) or not (BDG_SW2D_EVENT_NOFENCE=1), and whether the halo staging is folded into the
+    boundary kernel or done by separate pack / unpack kernels -- a missing dependency between the chains would show as a
+    difference between these runs (the ghost values are this rank's own elements: not physical, but deterministic)."""
+    from blitzdg_amd.halo import NativeDistributedSw2d
+    monkeypatch.setenv("BDG_SW2D_STRIP_THROUGHPUT", "1")       # N >= 5: both stagings on the same arithmetic
+    results = {}
+    for nofence in ("0", "1"):
+        for halo_kernels in ("", "1"):
+            monkeypatch.setenv("BDG_SW2D_EVENT_NOFENCE", nofence)
+            if halo_kernels:
+                monkeypatch.setenv("BDG_SW2D_HALO_KERNELS", "1")
+            else:
+                monkeypatch.delenv("BDG_SW2D_HALO_KERNELS", raising=False)
+            d = NativeDistributedSw2d.box(160, 80, order, 5, 8, device=0, loopback=True)
+            try:
+                d.set_initial_state(_fields)
+                dt = 0.25 * d.compute_dt(0.65)
+                for chunk in (3, 11, 23):
+                    d.lserk4_stages(dt, chunk)
+                d.barrier()
+                results[(nofence, halo_kernels)] = d.owned_state()[1:]
+            finally:
+                d.close()
+    ref = results[("0", "")]
+    assert np.isfinite(ref[0]).all() and np.abs(ref[1]).max() > 0
+    for key, got in results.items():
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), key
+
+
 # ---- the real multi-process path (one process per rank, the library's own communicator and stage loop) with a
 # ---- file-based stand-in for librccl.so, so that the ranks can share the single GPU of a test box
 
