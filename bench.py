@@ -125,7 +125,9 @@ def stage_kernel_name(order, elements, affine):
     """Name of the kernel a default LSERK4 stage launch of this size runs (blitzdg_amd/csrc/hip/sw2d_device.hip:
     unrolled vector kernel up to N=4 for large launches, matrix cores otherwise)."""
     if not affine:
-        return f"sw2d_stage_kernel<{order}, MODE_LSERK, false>"
+        if os.environ.get("BDG_SW2D_NODAL_VECTOR") and order <= 6:
+            return f"sw2d_stage_kernel<{order}, MODE_LSERK, false>"
+        return f"sw2d_stage_mfma3_kernel<{order}, MODE_LSERK, false, NODAL>"
     forced = os.environ.get("BDG_SW2D_AFFINE_VARIANT")
     if forced is not None:
         return f"BDG_SW2D_AFFINE_VARIANT={forced} <{order}, MODE_LSERK>"

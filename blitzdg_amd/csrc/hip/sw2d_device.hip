@@ -462,10 +462,16 @@ struct bdg_sw2d {
         } else if (affine) {
             p.opsAffine = filter ? opsAffineFiltered.p : opsAffine.p;
             hipCheck(kt->stageAffine(mode, variant, p, st), what);
+        } else if (nodalMfma) {
+            // per-node geometry on the matrix cores (state-once schedule), every order
+            p.opsAffine = filter ? opsMfma2NodalFilter.p : opsMfma2.p;
+            hipCheck(kt->stageMfma3Nodal(mode, filter, p, st), what);
         } else {
             hipCheck(kt->stage(mode, filter, p, st), what);
         }
     }
+    DevBuf<double> opsMfma2NodalFilter; // plain MfmaOps2 image + MT*KV Filter tiles
+    bool nodalMfma = false;   // non-affine tables: matrix-core kernel (default) instead of the N <= 6 vector kernel
     bool fastSources = false; // variants B/C/D on the unrolled kernels instead of the rolled ones
     bool lamExternal = false; // variant B, partitioned: lamBuf holds the all-rank speed of the state about to be evaluated
     // up to this order the unrolled source-term kernels are used, above it the matrix-core ones
@@ -1008,8 +1014,9 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     }
     if (reorder) s->permHost = bfsOrder(d.vmapP, K, Np, Nfp);
     s->affine = !(d.flags & BDG_SW2D_NODAL_GEOMETRY) && geometryIsAffine(d, Np, Nfp, K);
-    if (!s->affine && kt->ldsDoubles == 0)
-        throw arg_error("bdg_sw2d_create: orders above 6 are implemented for straight-sided (affine) geometry only");
+    // Non-affine tables: the matrix-core kernel with per-node geometry (every order). BDG_SW2D_NODAL_VECTOR=1 keeps the
+    // round-1 vector kernel (one lane per element, N <= 6) for A/B measurements and cross-checks.
+    s->nodalMfma = !s->affine && !(std::getenv("BDG_SW2D_NODAL_VECTOR") && kt->ldsDoubles != 0);
     if (!s->affine && s->variantD)
         throw arg_error("bdg_sw2d_create: tracer / source terms are implemented for straight-sided (affine) geometry only");
 
@@ -1051,7 +1058,7 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->qalt = s->qB.p;
 
     s->hasFilter = d.Filter != nullptr;
-    if (!s->affine) {
+    if (!s->affine && kt->ldsDoubles > 0) { // (orders 7, 8 have no vector kernel: matrix cores only)
         // ---- operator image for the nodal kernels: [Dr,Ds interleaved | Lift | Filter]
         std::vector<double> img(kt->ldsDoubles, 0.0);
         for (int i = 0; i < Np * Np; ++i) {
@@ -1091,6 +1098,59 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
             s->variantForced = true;
         }
     }
+    // the same operators as zero-padded 16x4 MFMA A tiles: lane l of tile (r, t) holds A[16r + (l&15)][4t + (l>>4)]
+    auto mfmaImage = [&](const double* Dr, const double* Ds, const double* Lift) {
+        const int MT = kt->mfmaMT, KV = kt->mfmaKV, KS = kt->mfmaKS;
+        std::vector<double> img(static_cast<size_t>(kt->mfmaOpsDoubles), 0.0);
+        auto fill = [&](size_t off, const double* A, int cols, int KT) {
+            for (int r = 0; r < MT; ++r)
+                for (int t = 0; t < KT; ++t)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = 16 * r + (l & 15), k = 4 * t + (l >> 4);
+                        if (i < Np && k < cols) img[off + (static_cast<size_t>(r) * KT + t) * 64 + l] = A[i * cols + k];
+                    }
+        };
+        fill(0, Dr, Np, KV);
+        fill(static_cast<size_t>(MT) * KV * 64, Ds, Np, KV);
+        fill(static_cast<size_t>(2) * MT * KV * 64, Lift, NFN, KS);
+        return img;
+    };
+    // face-by-face variant: lift tile (r, f, tf), lane l = Lift[16r + (l&15)][f*Nfp + 4tf + (l>>4)]
+    auto mfma2Image = [&](const double* Dr, const double* Ds, const double* Lift) {
+        const int MT = kt->mfmaMT, KV = kt->mfmaKV, KF = kt->mfma2KF;
+        std::vector<double> img(static_cast<size_t>(kt->mfma2OpsDoubles), 0.0);
+        const std::vector<double> first = mfmaImage(Dr, Ds, Lift);
+        std::copy(first.begin(), first.begin() + static_cast<size_t>(2) * MT * KV * 64, img.begin());
+        const size_t off = static_cast<size_t>(2) * MT * KV * 64;
+        for (int r = 0; r < MT; ++r)
+            for (int f = 0; f < 3; ++f)
+                for (int tf = 0; tf < KF; ++tf)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = 16 * r + (l & 15), n = 4 * tf + (l >> 4);
+                        if (i < Np && n < Nfp)
+                            img[off + ((static_cast<size_t>(r) * 3 + f) * KF + tf) * 64 + l] = Lift[i * NFN + f * Nfp + n];
+                    }
+        return img;
+    };
+    if (s->nodalMfma) { // per-node geometry on the matrix cores: the MfmaOps2 image, plain and pre-filtered
+        const std::vector<double> img2 = mfma2Image(d.Dr, d.Ds, d.Lift);
+        s->opsMfma2.alloc(img2.size(), s->bytes);
+        hipCheck(hipMemcpy(s->opsMfma2.p, img2.data(), img2.size() * sizeof(double), hipMemcpyHostToDevice), "mfma2 ops upload");
+        if (d.Filter) { // the filter follows the metric terms: plain operators, then the Filter's own tiles (r, t)
+            std::vector<double> imgF = img2;
+            const int MT = kt->mfmaMT, KV = kt->mfmaKV;
+            imgF.resize(img2.size() + static_cast<size_t>(MT) * KV * 64, 0.0);
+            for (int r = 0; r < MT; ++r)
+                for (int t = 0; t < KV; ++t)
+                    for (int l = 0; l < 64; ++l) {
+                        const int i = 16 * r + (l & 15), k = 4 * t + (l >> 4);
+                        if (i < Np && k < Np) imgF[img2.size() + (static_cast<size_t>(r) * KV + t) * 64 + l] = d.Filter[i * Np + k];
+                    }
+            s->opsMfma2NodalFilter.alloc(imgF.size(), s->bytes);
+            hipCheck(hipMemcpy(s->opsMfma2NodalFilter.p, imgF.data(), imgF.size() * sizeof(double), hipMemcpyHostToDevice),
+                     "nodal filter ops upload");
+        }
+    }
     if (s->affine) {
         s->ageo.alloc(13 * static_cast<size_t>(ld), s->bytes);
         hipCheck(hipMemsetAsync(s->ageo.p, 0, s->ageo.n * sizeof(double), s->stream), "hipMemset");
@@ -1108,40 +1168,6 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
         s->opsAffine.alloc(plain.size(), s->bytes);
         hipCheck(hipMemcpy(s->opsAffine.p, plain.data(), plain.size() * sizeof(double), hipMemcpyHostToDevice),
                  "affine ops upload");
-        // the same operators as zero-padded 16x4 MFMA A tiles: lane l of tile (r, t) holds A[16r + (l&15)][4t + (l>>4)]
-        auto mfmaImage = [&](const double* Dr, const double* Ds, const double* Lift) {
-            const int MT = kt->mfmaMT, KV = kt->mfmaKV, KS = kt->mfmaKS;
-            std::vector<double> img(static_cast<size_t>(kt->mfmaOpsDoubles), 0.0);
-            auto fill = [&](size_t off, const double* A, int cols, int KT) {
-                for (int r = 0; r < MT; ++r)
-                    for (int t = 0; t < KT; ++t)
-                        for (int l = 0; l < 64; ++l) {
-                            const int i = 16 * r + (l & 15), k = 4 * t + (l >> 4);
-                            if (i < Np && k < cols) img[off + (static_cast<size_t>(r) * KT + t) * 64 + l] = A[i * cols + k];
-                        }
-            };
-            fill(0, Dr, Np, KV);
-            fill(static_cast<size_t>(MT) * KV * 64, Ds, Np, KV);
-            fill(static_cast<size_t>(2) * MT * KV * 64, Lift, NFN, KS);
-            return img;
-        };
-        // face-by-face variant: lift tile (r, f, tf), lane l = Lift[16r + (l&15)][f*Nfp + 4tf + (l>>4)]
-        auto mfma2Image = [&](const double* Dr, const double* Ds, const double* Lift) {
-            const int MT = kt->mfmaMT, KV = kt->mfmaKV, KF = kt->mfma2KF;
-            std::vector<double> img(static_cast<size_t>(kt->mfma2OpsDoubles), 0.0);
-            const std::vector<double> first = mfmaImage(Dr, Ds, Lift);
-            std::copy(first.begin(), first.begin() + static_cast<size_t>(2) * MT * KV * 64, img.begin());
-            const size_t off = static_cast<size_t>(2) * MT * KV * 64;
-            for (int r = 0; r < MT; ++r)
-                for (int f = 0; f < 3; ++f)
-                    for (int tf = 0; tf < KF; ++tf)
-                        for (int l = 0; l < 64; ++l) {
-                            const int i = 16 * r + (l & 15), n = 4 * tf + (l >> 4);
-                            if (i < Np && n < Nfp)
-                                img[off + ((static_cast<size_t>(r) * 3 + f) * KF + tf) * 64 + l] = Lift[i * NFN + f * Nfp + n];
-                        }
-            return img;
-        };
         {
             const std::vector<double> img2 = mfma2Image(d.Dr, d.Ds, d.Lift);
             s->opsMfma2.alloc(img2.size(), s->bytes);

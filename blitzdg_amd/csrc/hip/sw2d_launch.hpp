@@ -31,6 +31,8 @@ struct KernelTable {
     // sources, no halo staging): sw2d_mfma3_kernel.hpp
     hipError_t (*stageMfma3)(int mode, const StageParams& p, hipStream_t stream);
     hipError_t (*stageMfma3Halo)(const StageParams& p, hipStream_t stream); // MODE_LSERK with the halo staging folded in
+    // per-node geometry (geo / fgeo planes); filter: plain operators + MT*KV Filter tiles in the image
+    hipError_t (*stageMfma3Nodal)(int mode, bool filter, const StageParams& p, hipStream_t stream);
     // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the
     // tracer-equation pass (plain MfmaOps2 image); tracer = 2: variant B (image as for the sources)
     hipError_t (*stageMfma2Src)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);

@@ -74,19 +74,33 @@ struct Mfma3Lds {
 // sw2d_stage_mfma_kernel -- a neighbour trace that lives in a ghost slot is read from the received record, and the new
 // state of an element is also written to its (up to three) send records. Same arithmetic as HALO = false, so a
 // partitioned run reproduces the single-domain run bit for bit.
-template <int N, int MODE, bool HALO = false>
+// NODAL: per-node geometry (callers whose tables are not those of straight-sided elements: rx, sx, ry, sy at every node
+// in StageParams::geo, nx, ny, Fscale at every face node in StageParams::fgeo) instead of the 13 per-element values.
+// With metric terms that vary inside an element the reference's form is R_c[i] = -(rx_i (Dr F_c)_i + sx_i (Ds F_c)_i +
+// ry_i (Dr G_c)_i + sy_i (Ds G_c)_i) -- the metric multiplies AFTER the differentiation, at the output node -- so the
+// volume term keeps ten products apart (Dr and Ds of the five distinct flux functions hu, hv, F2, G2, G3: 10 MT
+// accumulators, 10 MT KV matrix instructions) and combines them with the output nodes' metric rows, requested during the
+// last k-steps, before the faces are added. A face's normals and scales are requested for the next tile when the face
+// is finished, like its neighbour traces.
+// NFILT (NODAL only): the result is Filter * RHS. With the metric applied after the differentiation the filter cannot be
+// folded into the operators (Filter (rx o Dr F) != rx o (Filter Dr) F): the image carries MT KV Filter tiles behind the
+// plain operators, and the finished RHS -- accumulator layout = operand layout -- goes through one more product.
+template <int N, int MODE, bool HALO = false, bool NODAL = false, bool NFILT = false>
 __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StageParams p) {
     static_assert(!HALO || MODE == MODE_LSERK, "halo staging is folded into LSERK stages only");
+    static_assert(!(HALO && NODAL), "partitioned runs use the straight-sided form");
+    static_assert(NODAL || !NFILT, "straight-sided elements take the filter through pre-multiplied operators");
     using E = Elem<N>;
     using O = MfmaOps2<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
 
+    constexpr int IMAGE = O::DOUBLES + (NFILT ? MT * KV * 64 : 0); // [+ Filter tiles (r, t)]
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    for (int t = threadIdx.x; t < IMAGE; t += blockDim.x) sOps[t] = p.opsAffine[t];
     __syncthreads();
     // this wave's state tile; indexed through sOps so that the accesses stay LDS instructions (a generic pointer
     // would turn them into flat_load / flat_store, which also wait for every outstanding global load)
-    const int sBase = O::DOUBLES + static_cast<int>(threadIdx.x >> 6) * Mfma3Lds<N>::TILE_DOUBLES + static_cast<int>(threadIdx.x & 15u);
+    const int sBase = IMAGE + static_cast<int>(threadIdx.x >> 6) * Mfma3Lds<N>::TILE_DOUBLES + static_cast<int>(threadIdx.x & 15u);
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
     const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
@@ -110,7 +124,15 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         rout[c] = plane_rsrc((MODE == MODE_RHS ? p.rhs : p.qout) + c * plane, planeBytes);
         rres[c] = plane_rsrc((MODE == MODE_LSERK ? p.res : p.qin) + c * plane, planeBytes);
     }
-    const __amdgpu_buffer_rsrc_t rgeo = plane_rsrc(p.ageo, 13u * ld8), ridx = plane_rsrc(p.vmapP, 3u * Nfp * ld4);
+    const __amdgpu_buffer_rsrc_t rgeo = plane_rsrc(NODAL ? p.geo : p.ageo, NODAL ? planeBytes : 13u * ld8),
+                                 ridx = plane_rsrc(p.vmapP, 3u * Nfp * ld4);
+    // nodal geometry: rx, sx, ry, sy planes of Np rows; nx, ny, Fscale planes of 3 Nfp rows
+    __amdgpu_buffer_rsrc_t rmet[4], rfg[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rmet[i] = plane_rsrc(NODAL ? p.geo + i * plane : p.ageo, NODAL ? planeBytes : 8u);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        rfg[i] = plane_rsrc(NODAL ? p.fgeo + static_cast<long long>(i) * 3 * Nfp * ld : p.ageo, NODAL ? 3u * Nfp * ld8 : 8u);
     // received ghost records [ghost][field][node] (HALO); the descriptor is never used otherwise
     const __amdgpu_buffer_rsrc_t rrecv = plane_rsrc(HALO ? p.haloRecv : p.ageo, 0xffffffffu);
 
@@ -136,8 +158,26 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                 ix[f][tf] = bld_i32(ridx, (4 * tf + static_cast<int>(q) < Nfp) ? v4 : 0xfffffffcu, static_cast<unsigned>(f * Nfp + 4 * tf) * ld4);
     };
     auto loadGeometry = [&](unsigned kk, double (&gg)[13]) {
+        if constexpr (!NODAL) {
 #pragma unroll
-        for (int i = 0; i < 13; ++i) gg[i] = bld_f64(rgeo, kk * 8u, static_cast<unsigned>(i) * ld8);
+            for (int i = 0; i < 13; ++i) gg[i] = bld_f64(rgeo, kk * 8u, static_cast<unsigned>(i) * ld8);
+        }
+    };
+    auto loadMetricRow = [&](unsigned kk, int t, double (&mm)[4]) { // rx, sx, ry, sy at node 4 t + q
+        const unsigned v8 = (q * static_cast<unsigned>(ld) + kk) * 8u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mm[i] = bld_f64(rmet[i], row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
+    };
+    auto loadFaceGeometry = [&](int f, unsigned kk, double (&fx)[3][KF], double (&fy)[3][KF], double (&fs)[3][KF]) {
+        const unsigned v8 = (q * static_cast<unsigned>(ld) + kk) * 8u;
+#pragma unroll
+        for (int tf = 0; tf < KF; ++tf) {
+            const unsigned vo = (4 * tf + static_cast<int>(q) < Nfp) ? v8 : 0xfffffff8u;
+            const unsigned so = static_cast<unsigned>(f * Nfp + 4 * tf) * ld8;
+            fx[f][tf] = bld_f64(rfg[0], vo, so);
+            fy[f][tf] = bld_f64(rfg[1], vo, so);
+            fs[f][tf] = bld_f64(rfg[2], vo, so);
+        }
     };
     // neighbour traces of face f (face node n = 4 tf + q); lanes beyond the face read node 0 of element 0 and ignore it
     auto loadTraces = [&](int f, const int (&ix)[3][KF], double (&a)[3][KF], double (&b)[3][KF], double (&c3)[3][KF]) {
@@ -172,6 +212,12 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
     loadGeometry(k, geo);
 #pragma unroll
     for (int f = 0; f < 3; ++f) loadTraces(f, fidx, hP, huP, hvP);
+    // nodal geometry of the first tile: all face normals / scales
+    double fnx[3][KF], fny[3][KF], fsc[3][KF];
+    if constexpr (NODAL) {
+#pragma unroll
+        for (int f = 0; f < 3; ++f) loadFaceGeometry(f, k, fnx, fny, fsc);
+    }
 
 #pragma unroll 1
     for (;;) {
@@ -182,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         // next tile, requested piece by piece below as this tile's registers fall free
         double qN[3][KV], geoN[13], hPN[3][KF], huPN[3][KF], hvPN[3][KF];
         int fidxN[3][KF];
+        double fnxN[3][KF], fnyN[3][KF], fscN[3][KF];
 
         // ---- own state into the wave's LDS tile (face traces and the update read it back from there)
 #pragma unroll
@@ -199,7 +246,6 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
 #pragma unroll
             for (int r = 0; r < MT; ++r) acc[c][r] = mfma_zero(); // not a literal 0: see mfma_zero
 
-        const double rx = geo[0], sx = geo[1], ry = geo[2], sy = geo[3];
         // volume term, software pipelined by hand: the six operands of k-step t + 1 are formed (vector ALU) in the same
         // scheduling region as the 6 MT matrix instructions of k-step t, so the two pipes overlap within one wave; the
         // state rows of k-step t are dead by then and the same rows of the NEXT tile are requested in their place
@@ -212,9 +258,15 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             const double pr = halfg * h * h;
             const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
             const double w = pad ? 0.0 : -1.0; // zero the padded rows of the operand
-            ab[0] = w * (rx * hu + ry * hv); ab[1] = w * (sx * hu + sy * hv);
-            ab[2] = w * (rx * F2 + ry * G2); ab[3] = w * (sx * F2 + sy * G2);
-            ab[4] = w * (rx * G2 + ry * G3); ab[5] = w * (sx * G2 + sy * G3);
+            if constexpr (NODAL) { // the five distinct flux functions themselves (metric terms come after the products)
+                ab[0] = pad ? 0.0 : hu; ab[1] = pad ? 0.0 : hv; ab[2] = pad ? 0.0 : F2; ab[3] = pad ? 0.0 : G2;
+                ab[4] = pad ? 0.0 : G3; ab[5] = 0.0;
+            } else {
+                const double rx = geo[0], sx = geo[1], ry = geo[2], sy = geo[3];
+                ab[0] = w * (rx * hu + ry * hv); ab[1] = w * (sx * hu + sy * hv);
+                ab[2] = w * (rx * F2 + ry * G2); ab[3] = w * (sx * F2 + sy * G2);
+                ab[4] = w * (rx * G2 + ry * G3); ab[5] = w * (sx * G2 + sy * G3);
+            }
         };
         // Pointwise work of the surface term (face node n = 4 tf + q of face f; '-' traces from the LDS tile, '+' traces
         // prefetched during the previous tile), one face node per lane at a time: it is spread over the volume k-steps,
@@ -223,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         double sF[3][3][KF];
         double eF[3][KF], dF[3][KF], lamF = 0.0;
         auto faceNode = [&](int f, int tf) {
-            const double nxf = geo[4 + f], nyf = geo[7 + f];
+            const double nxf = NODAL ? fnx[f][tf] : geo[4 + f], nyf = NODAL ? fny[f][tf] : geo[7 + f];
             const int n = 4 * tf + static_cast<int>(q);
 #pragma unroll
             for (int c = 0; c < 3; ++c) eF[c][tf] = dF[c][tf] = 0.0;
@@ -253,42 +305,91 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             if (tf == KF - 1) { // the face is complete: its speed (the face's nodes sit in the 4 lanes q of this element)
                 double lam = fmax(lamF, __shfl_xor(lamF, 16));
                 lam = fmax(lam, __shfl_xor(lam, 32));
-                const double hfs = 0.5 * geo[10 + f];
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int t2 = 0; t2 < KF; ++t2) {
+                    const double hfs = 0.5 * (NODAL ? fsc[f][t2] : geo[10 + f]);
 #pragma unroll
-                    for (int t2 = 0; t2 < KF; ++t2) sF[f][c][t2] = hfs * (eF[c][t2] - lam * dF[c][t2]);
+                    for (int c = 0; c < 3; ++c) sF[f][c][t2] = hfs * (eF[c][t2] - lam * dF[c][t2]);
+                }
                 lamF = 0.0;
                 loadTraces(f, fidxN, hPN, huPN, hvPN); // this face's '+' traces are dead: request the next tile's
+                if constexpr (NODAL) loadFaceGeometry(f, kN, fnxN, fnyN, fscN);
             }
         };
         constexpr int FACE_ITEMS = 3 * KF, PER_STEP = (FACE_ITEMS + KV - 1) / KV;
 
-        double abCur[6], abNext[6];
-        volumeOperands(0, abCur);
-        loadIndices(kN, fidxN);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < KV; ++t) {
-            if (t + 1 < KV) volumeOperands(t + 1, abNext);
-            loadStateRow(kN, t, qN);
-#pragma unroll
-            for (int it = t * PER_STEP; it < (t + 1) * PER_STEP; ++it)
-                if (it < FACE_ITEMS) faceNode(it / KF, it % KF);
-#pragma unroll
-            for (int r2 = 0; r2 < MT; ++r2) {
-                const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
-                const double Ads = sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane];
-                acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[0], acc[0][r2], 0, 0, 0);
-                acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[2], acc[1][r2], 0, 0, 0);
-                acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[4], acc[2][r2], 0, 0, 0);
-                acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[1], acc[0][r2], 0, 0, 0);
-                acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[3], acc[1][r2], 0, 0, 0);
-                acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[5], acc[2][r2], 0, 0, 0);
-            }
+        if constexpr (!NODAL) {
+            double abCur[6], abNext[6];
+            volumeOperands(0, abCur);
+            loadIndices(kN, fidxN);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) abCur[i] = abNext[i];
+            for (int t = 0; t < KV; ++t) {
+                if (t + 1 < KV) volumeOperands(t + 1, abNext);
+                loadStateRow(kN, t, qN);
+#pragma unroll
+                for (int it = t * PER_STEP; it < (t + 1) * PER_STEP; ++it)
+                    if (it < FACE_ITEMS) faceNode(it / KF, it % KF);
+#pragma unroll
+                for (int r2 = 0; r2 < MT; ++r2) {
+                    const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
+                    const double Ads = sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane];
+                    acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[0], acc[0][r2], 0, 0, 0);
+                    acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[2], acc[1][r2], 0, 0, 0);
+                    acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[4], acc[2][r2], 0, 0, 0);
+                    acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[1], acc[0][r2], 0, 0, 0);
+                    acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[3], acc[1][r2], 0, 0, 0);
+                    acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[5], acc[2][r2], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) abCur[i] = abNext[i];
+            }
+        } else {
+            // One 16-row block of output nodes at a time: av[2 i] = Dr s_i, av[2 i + 1] = Ds s_i for the five flux functions
+            // s = (hu, hv, F2, G2, G3) (their values are formed again in every pass: a few dozen vector instructions against
+            // 10 matrix instructions per k-step), then the block's rows R_c = -(rx Dr F_c + sx Ds F_c + ry Dr G_c + sy Ds G_c)
+            // with the metric rows of the block's own nodes. The next tile's state is requested during the last pass.
+            loadIndices(kN, fidxN);
+            constexpr int STEPS = MT * KV, PER = (FACE_ITEMS + STEPS - 1) / STEPS;
+#pragma unroll
+            for (int r = 0; r < MT; ++r) {
+                double met[4][4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * r + e < KV) loadMetricRow(k, 4 * r + e, met[e]);
+                mfma_acc_t av[10];
+#pragma unroll
+                for (int i = 0; i < 10; ++i) av[i] = mfma_zero();
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < KV; ++t) {
+                    double fl[6];
+                    volumeOperands(t, fl);
+                    if (r == MT - 1) loadStateRow(kN, t, qN);
+#pragma unroll
+                    for (int it = (r * KV + t) * PER; it < (r * KV + t + 1) * PER; ++it)
+                        if (it < FACE_ITEMS) faceNode(it / KF, it % KF);
+                    const double Adr = sOps[O::OFF_DR + (r * KV + t) * 64 + lane];
+                    const double Ads = sOps[O::OFF_DS + (r * KV + t) * 64 + lane];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        av[2 * i] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, fl[i], av[2 * i], 0, 0, 0);
+                        av[2 * i + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, fl[i], av[2 * i + 1], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * r + e < KV) {
+                        const double rx = met[e][0], sx = met[e][1], ry = met[e][2], sy = met[e][3]; // 0 on padding rows
+                        // F = (hu, F2, G2), G = (hv, G2, G3); av: 0,1 hu | 2,3 hv | 4,5 F2 | 6,7 G2 | 8,9 G3
+                        acc[0][r][e] = -(rx * av[0][e] + sx * av[1][e] + ry * av[2][e] + sy * av[3][e]);
+                        acc[1][r][e] = -(rx * av[4][e] + sx * av[5][e] + ry * av[6][e] + sy * av[7][e]);
+                        acc[2][r][e] = -(rx * av[6][e] + sx * av[7][e] + ry * av[8][e] + sy * av[9][e]);
+                    }
+                }
+            }
         }
 
         // ---- residual (LSERK) / base state (COMBINE) rows of this tile, consumed by the update after the faces
@@ -315,6 +416,27 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                     acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][2][tf], acc[2][r], 0, 0, 0);
                 }
         __builtin_amdgcn_sched_barrier(0);
+
+        if constexpr (NFILT) { // RHS <- Filter * RHS: the accumulators are the operands of one more product
+            mfma_acc_t fo[3][MT];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < MT; ++r) fo[c][r] = mfma_zero();
+#pragma unroll
+            for (int t = 0; t < KV; ++t)
+#pragma unroll
+                for (int r = 0; r < MT; ++r) {
+                    const double Af = sOps[O::DOUBLES + (r * KV + t) * 64 + lane];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        fo[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af, acc[c][t >> 2][t & 3], fo[c][r], 0, 0, 0);
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int r = 0; r < MT; ++r) acc[c][r] = fo[c][r];
+        }
 
         // ---- stage update / output: node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3); stores of the
         //      padding rows carry an out-of-range vector offset (row_voffset) and are dropped, padding lanes store nothing
@@ -371,7 +493,9 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             for (int tf = 0; tf < KF; ++tf) {
                 fidx[f][tf] = fidxN[f][tf];
                 hP[f][tf] = hPN[f][tf]; huP[f][tf] = huPN[f][tf]; hvP[f][tf] = hvPN[f][tf];
+                if constexpr (NODAL) { fnx[f][tf] = fnxN[f][tf]; fny[f][tf] = fnyN[f][tf]; fsc[f][tf] = fscN[f][tf]; }
             }
+
     }
 }
 

@@ -226,11 +226,11 @@ hipError_t launchMfma2(const StageParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int MODE>
+template <int MODE, bool NODAL = false, bool NFILT = false>
 hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
     if (p.kend <= p.kbegin) return hipSuccess;
-    const size_t ldsBytes = sizeof(double) * Mfma3Lds<kN>::DOUBLES;
-    auto kern = sw2d_stage_mfma3_kernel<kN, MODE>;
+    const size_t ldsBytes = sizeof(double) * (Mfma3Lds<kN>::DOUBLES + (NFILT ? MfmaOps2<kN>::MT * MfmaOps2<kN>::KV * 64 : 0));
+    auto kern = sw2d_stage_mfma3_kernel<kN, MODE, false, NODAL, NFILT>;
     if (ldsBytes > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(ldsBytes));
@@ -241,6 +241,17 @@ hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
     const unsigned grid = std::min((ntiles + 3u) / 4u, cap); // one four-wave workgroup per CU, one wave per SIMD
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
+}
+
+// per-node geometry (StageParams::geo / fgeo) on the same schedule
+// filter: the image in p.opsAffine carries the Filter tiles behind the plain operators
+hipError_t stageMfma3Nodal(int mode, bool filter, const StageParams& p, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return filter ? launchMfma3<MODE_RHS, true, true>(p, stream) : launchMfma3<MODE_RHS, true>(p, stream);
+    case MODE_LSERK: return filter ? hipErrorInvalidValue : launchMfma3<MODE_LSERK, true>(p, stream);
+    case MODE_COMBINE: return filter ? launchMfma3<MODE_COMBINE, true, true>(p, stream) : launchMfma3<MODE_COMBINE, true>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // one LSERK4 stage of the partition-boundary elements with the halo staging folded in, state-once schedule
@@ -399,7 +410,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, &stageMfma2Halo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
+                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma3Nodal, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

@@ -39,11 +39,7 @@ def solver_from_case(d, flags=0):
 @pytest.mark.parametrize("flags", [0, sw2d.REORDER, sw2d.NODAL_GEOMETRY, sw2d.NODAL_GEOMETRY | sw2d.REORDER])
 def test_rhs_matches_reference_fixture(case, flags):
     d = load_case(case)
-    if int(d["order"]) > 6 and flags & sw2d.NODAL_GEOMETRY:
-        with pytest.raises(BdgError, match="affine"):
-            solver_from_case(d, flags)  # orders 7, 8: field-split kernels, straight-sided elements only
-        return
-    s = solver_from_case(d, flags)
+    s = solver_from_case(d, flags)  # NODAL_GEOMETRY: the matrix-core kernel with per-node geometry, every order
     assert s.usesAffineGeometry == (not flags & sw2d.NODAL_GEOMETRY)  # all fixtures are straight-sided
     r = s.computeRHS(d["h"], d["hu"], d["hv"])
     scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
@@ -240,8 +236,6 @@ def test_medium_box_meshes_vs_oracle(order, nx, ny, seed):
     dt = 0.5 * o.dt(h, hu, hv, 0.65, order)
     ref_state = o.step_lserk4(h, hu, hv, dt, 2)
     for flags in (0, sw2d.REORDER, sw2d.KEEP_ORDER, sw2d.NODAL_GEOMETRY):
-        if order > 6 and flags & sw2d.NODAL_GEOMETRY:
-            continue
         s = sw2d.Sw2dSolver(nodes=nodes, flags=flags)
         r = s.computeRHS(h, hu, hv)
         assert max(np.abs(a - b).max() for a, b in zip(r, ref)) / scale < RHS_TOL
@@ -675,6 +669,68 @@ def test_every_affine_kernel_variant_matches_the_reference_fixture(variant, case
     zero = [np.zeros_like(d["h"]) for _ in range(3)]
     ref = o.lserk4_stages(d["h"], d["hu"], d["hv"], zero, dt, 0, 7)
     for a, b in zip(s.getState(), ref[:3]):
+        assert relmax(a, b) < STATE_TOL
+
+
+@pytest.mark.parametrize("order,nx,ny", [(1, 41, 33), (2, 29, 31), (4, 37, 25), (6, 23, 19), (8, 17, 15)])
+@pytest.mark.parametrize("vector", [False, True])
+def test_non_affine_tables_on_the_matrix_core_kernel(order, nx, ny, vector, monkeypatch):
+    """Tables that are NOT those of straight-sided elements -- the metric terms and normals of a smoothly deformed mesh,
+    recomputed per node (what buildCubatureVolumeMesh leaves in the provisioner) -- go to the matrix-core kernel with
+    per-node geometry (sw2d_stage_mfma3_kernel<..., NODAL>), every order, several tiles per wave, ragged last tile:
+    RHS (plain and filtered) against the C oracle fed with the same tables, 9 LSERK4 stages and a midpoint-RK2 + filter
+    step against the oracle's. vector=True: round 1's vector kernel (N <= 6; BDG_SW2D_NODAL_VECTOR=1) on the same input."""
+    if vector:
+        if order > 6:
+            pytest.skip("the vector kernel exists up to N = 6")
+        monkeypatch.setenv("BDG_SW2D_NODAL_VECTOR", "1")
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(nx, ny, shuffleSeed=77)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, max(order, 2))
+    ctx = nodes.dgContext()
+    x0, y0 = ctx.x, ctx.y
+    x = x0 + 0.06 * np.sin(2.1 * y0) * (1 - x0 * x0)
+    y = y0 + 0.05 * np.sin(2.7 * x0 + 0.3) * (1 - y0 * y0)
+    # per-node metric terms and face geometry of the deformed elements, as the reference's formulas give them
+    # (src/TriangleNodesProvisioner.cpp:810-892), from this repository's Dr / Ds
+    Dr, Ds = ctx.Dr, ctx.Ds
+    xr, xs, yr, ys = Dr @ x, Ds @ x, Dr @ y, Ds @ y
+    J = xr * ys - xs * yr
+    assert J.min() > 0
+    t = tables_from_nodes(nodes)
+    t.update(rx=ys / J, sx=-yr / J, ry=-xs / J, sy=xr / J, x=x, y=y)
+    Fm = ctx.Fmask.T.reshape(-1) if ctx.Fmask.shape[0] == order + 1 else ctx.Fmask.reshape(-1)
+    Nfp = order + 1
+    fxr, fxs, fyr, fys = xr[Fm], xs[Fm], yr[Fm], ys[Fm]
+    nxf, nyf = np.empty_like(fxr), np.empty_like(fxr)
+    nxf[:Nfp], nyf[:Nfp] = fyr[:Nfp], -fxr[:Nfp]
+    nxf[Nfp:2 * Nfp], nyf[Nfp:2 * Nfp] = fys[Nfp:2 * Nfp] - fyr[Nfp:2 * Nfp], -fxs[Nfp:2 * Nfp] + fxr[Nfp:2 * Nfp]
+    nxf[2 * Nfp:], nyf[2 * Nfp:] = -fys[2 * Nfp:], fxs[2 * Nfp:]
+    sJ = np.hypot(nxf, nyf)
+    t.update(nx=nxf / sJ, ny=nyf / sJ, Fscale=sJ / J[Fm])
+    # (three-node elements stay straight whatever the map: at N = 1 the per-node path is asked for explicitly)
+    s = sw2d.Sw2dSolver(tables=t, g=9.81, flags=sw2d.KEEP_ORDER | (sw2d.NODAL_GEOMETRY if order == 1 else 0))
+    assert not s.usesAffineGeometry
+    o = oracle_from(t, threads=4)
+    h, hu, hv = seeded_fields(x, y, seed=order)
+    ref = o.rhs(h, hu, hv)
+    scale = max(np.abs(r).max() for r in ref)
+    got = s.computeRHS(h, hu, hv)
+    assert max(np.abs(a - b).max() for a, b in zip(got, ref)) / scale < RHS_TOL
+    gotf = s.computeRHS(h, hu, hv, filter=True)
+    assert max(np.abs(a - t["Filter"] @ b).max() for a, b in zip(gotf, ref)) / scale < RHS_TOL
+    dt = 0.3 * o.dt(h, hu, hv, 0.65, order)
+    s.setState(h, hu, hv)
+    s.lserk4Stages(dt, 9)
+    zero = [np.zeros_like(h) for _ in range(3)]
+    ref9 = o.lserk4_stages(h, hu, hv, zero, dt, 0, 9)
+    for a, b in zip(s.getState(), ref9[:3]):
+        assert relmax(a, b) < STATE_TOL
+    s.setState(h, hu, hv)
+    s.stepRK2(dt, 2, filter=True)
+    refk = o.step_rk2(h, hu, hv, dt, 2, filter=True)
+    for a, b in zip(s.getState(), refk):
         assert relmax(a, b) < STATE_TOL
 
 
