@@ -6,6 +6,7 @@
 #include "sw2d_curved_kernel.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -77,7 +78,9 @@ struct bdg_sw2d_curved {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t bytes = 0;
     Buf<double> qA, qB, res, rhs, gq, cubG, gaussG, rJ, zx, zy, fcor, cd, mmSide, cholSide, ops, filt;
-    Buf<int> gmapP, gmapM, curvedSlot, curvedEls;
+    Buf<int> gmapP, gmapM, curvedSlot, curvedEls, affineEl;
+    Buf<double> cubAffine, cubWref;
+    int numAffine = 0;
     double g = 9.81, fconst = 0.0, cdconst = 0.0;
     long long stageCount = 0;
     double bytesPerElement = 0.0;
@@ -110,6 +113,7 @@ struct bdg_sw2d_curved {
         p.rJ = rJ.p; p.zx = zx.p; p.zy = zy.p; p.fcor = fcor.p; p.cd = cd.p; p.fconst = fconst; p.cdconst = cdconst;
         p.curvedSlot = numCurved ? curvedSlot.p : nullptr;
         p.mmSide = mmSide.p; p.cholSide = cholSide.p; p.curvedEls = curvedEls.p; p.numCurved = numCurved; p.sideLd = sideLd;
+        p.affineEl = numAffine ? affineEl.p : nullptr; p.cubAffine = numAffine ? cubAffine.p : nullptr; p.cubWref = cubWref.p;
         p.ops = ops.p; p.filt = filt.p; p.ld = ld; p.K = K; p.ncb = ncb; p.ncub = ncub; p.ng = ng; p.fb = fb; p.g = g;
         return p;
     }
@@ -246,6 +250,55 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
             s->uploadRows(tmp.data(), s->cubG.p + static_cast<size_t>(t) * CR * ld, Ncub);
         }
     }
+    // ---- straight-sided elements: rx, ry, sx, sy do not vary over the cubature points and W[i] = w_i J, so the four
+    //      Ncub-row planes are 4 numbers per element times one vector of weights. Found here from the tables themselves
+    //      (to 1e-10 relative -- the tables of a fine mesh carry that much round-off from Dr x; the reference element is the first one with constant metric terms):
+    //      (W rx)[i, k] = Wref[i] * (W[0, k] / Wref[0]) * rx[0, k]. BDG_SW2D_CURVED_NO_AFFINE=1 keeps every element general.
+    if (!std::getenv("BDG_SW2D_CURVED_NO_AFFINE")) {
+        const double* geo[4] = {d.cubrx, d.cubry, d.cubsx, d.cubsy};
+        std::vector<int> flag(static_cast<size_t>(ld), 0);
+        auto constantMetric = [&](int k) {
+            for (int t = 0; t < 4; ++t) {
+                const double v0 = geo[t][k];
+                double scale = 0.0;
+                for (int t2 = 0; t2 < 4; ++t2) scale = std::max(scale, std::fabs(geo[t2][k]));
+                for (int i = 1; i < Ncub; ++i)
+                    if (std::fabs(geo[t][static_cast<size_t>(i) * K + k] - v0) > 1e-10 * scale) return false;
+            }
+            return true;
+        };
+        int kref = -1;
+        for (int k = 0; k < K && kref < 0; ++k)
+            if (constantMetric(k) && d.cubW[k] > 0.0) kref = k;
+        if (kref >= 0) {
+            std::vector<double> wref(static_cast<size_t>(CR), 0.0), ca(static_cast<size_t>(4) * K, 0.0);
+            for (int i = 0; i < Ncub; ++i) wref[i] = d.cubW[static_cast<size_t>(i) * K + kref];
+            int count = 0;
+#pragma omp parallel for schedule(static) reduction(+ : count)
+            for (int k = 0; k < K; ++k) {
+                if (slotOf[k] >= 0 || !constantMetric(k)) continue; // elements of curvedEls keep the general path
+                const double ratio = d.cubW[k] / wref[0];
+                bool ok = ratio > 0.0;
+                for (int i = 1; i < Ncub && ok; ++i)
+                    ok = std::fabs(d.cubW[static_cast<size_t>(i) * K + k] - ratio * wref[i]) <= 1e-10 * std::fabs(ratio * wref[i]);
+                if (!ok) continue;
+                flag[k] = 1;
+                for (int t = 0; t < 4; ++t) ca[static_cast<size_t>(t) * K + k] = ratio * geo[t][k];
+                ++count;
+            }
+            s->numAffine = count;
+            if (count) {
+                for (long long k = K; k < ld; ++k) flag[k] = flag[K - 1]; // (padding lanes repeat the last element)
+                s->affineEl.alloc(static_cast<size_t>(ld), s->bytes, st);
+                hipOk(hipMemcpyAsync(s->affineEl.p, flag.data(), flag.size() * sizeof(int), hipMemcpyHostToDevice, st), "affine flags upload");
+                s->cubAffine.alloc(static_cast<size_t>(4) * ld, s->bytes, st);
+                s->uploadRows(ca.data(), s->cubAffine.p, 4);
+                s->cubWref.alloc(wref.size(), s->bytes, st);
+                hipOk(hipMemcpyAsync(s->cubWref.p, wref.data(), wref.size() * sizeof(double), hipMemcpyHostToDevice, st), "Wref upload");
+                hipOk(hipStreamSynchronize(st), "affine upload sync");
+            }
+        }
+    }
     // ---- Gauss geometry nx, ny, W and the maps, each face padded to 16 fb rows
     s->gaussG.alloc(static_cast<size_t>(3) * GR * ld, s->bytes, st);
     {
@@ -369,9 +422,13 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         hipOk(hipStreamSynchronize(st), "ops sync");
     }
     // compulsory bytes of one RHS evaluation per element: state in, RHS out, geometry, maps, traces out and in (twice: both sides)
-    s->bytesPerElement = 8.0 * (4 * Np /*q*/ + 4 * Np /*out*/ + 4 * Ncub + 3 * NG3 + Np /*rJ*/ + (d.zx ? Np : 0) + (d.zy ? Np : 0) +
-                                (d.coriolis ? Np : 0) + (d.drag ? Np : 0) + 4 * Np /*q, trace kernel*/ + 3 * 4 * NG3 /*gq write, read M, read P*/) +
-                         4.0 * (NG3 * (identityM ? 1 : 2) + 1);
+    // state in, RHS out, cubature geometry (4 Ncub per general element, 4 per straight one), Gauss geometry, 1/J, sources,
+    // state again in the trace kernel, traces out and in (the exterior side; the interior side too when gmapM is not the identity)
+    const double fracAffine = static_cast<double>(s->numAffine) / K;
+    s->bytesPerElement = 8.0 * (4 * Np + 4 * Np + (1.0 - fracAffine) * 4 * Ncub + fracAffine * 4 + 3 * NG3 + Np + (d.zx ? Np : 0) +
+                                (d.zy ? Np : 0) + (d.coriolis ? Np : 0) + (d.drag ? Np : 0) + 4 * Np +
+                                (identityM ? 2 : 3) * 4 * NG3) +
+                         4.0 * (NG3 * (identityM ? 1 : 2) + 2);
     return s.release();
 }
 

@@ -65,6 +65,9 @@ struct CurvedParams {
     const int* curvedEls;  // element slot of each side-buffer column
     int numCurved;
     long long sideLd;
+    const int* affineEl;    // ld: 1 for straight-sided elements whose cubature geometry is held compressed (nullptr: none)
+    const double* cubAffine; // 4 rows of ld: the element's numbers c with (W rx, W ry, W sx, W sy)[i] = cubWref[i] * c
+    const double* cubWref;   // CR: W at the cubature points of a reference straight element (zero padded)
     const double* ops;    // operator image (CurvedOps layout), 64 doubles per tile
     const double* filt;   // (Np, Np) row-major filter for the fix-up kernel, or nullptr
     long long ld;
@@ -99,7 +102,7 @@ struct CurvedOps {
     __host__ __device__ static constexpr int offF(int ncb, int fb) { return offMF(ncb, fb) + MT * KV; }
     __host__ __device__ static constexpr int offGI(int ncb, int fb) { return offF(ncb, fb) + MT * KV; }
     __host__ __device__ static constexpr int tiles(int ncb, int fb) { return offGI(ncb, fb) + 3 * fb * KV; }
-    // the stage kernel reads [0, offGI)
+    // the stage kernel reads the whole image (the Gauss tiles GI for the element's own traces)
 };
 
 template <typename T>
@@ -220,10 +223,35 @@ __device__ __forceinline__ void curved_sources(const CurvedParams& p, double h, 
     S3 = -(f * hu - cdn * v) - p.g * h * zy;
 }
 
+// Buffer addressing (as in sw2d_mfma3_kernel.hpp): one wave-uniform descriptor per plane, ONE per-lane byte offset per tile
+// ((q ld + k) 8: lane (q, j) touches rows 4 t + q / 16 b + 4 reg + q of its element k) and the row group as scalar offset, so
+// no 64-bit address per load sits in vector registers. The hardware range check covers the vector offset only: lanes on
+// padding rows get an out-of-range one (loads return 0, stores are dropped).
+typedef unsigned int cbdg_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cplane_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double cbld_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+__device__ __forceinline__ int cbld_i32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return static_cast<int>(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void cbst_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(cbdg_u32x2, v), r, voff, soff, 0);
+}
+
 // MODE: CMODE_*; FILTER: the result is Filter * RHS (the drivers filter the whole RHS, sources included);
 // OPSLDS: operator tiles staged in LDS (else read from global memory / L2: images beyond the LDS budget);
 // FB: 16-row blocks per face (1: NGauss <= 16, 2: NGauss <= 32); WAVES: waves per SIMD the register budget is set for.
-template <int N, int MODE, bool FILTER, bool OPSLDS, int FB, int WAVES>
+//
+// Two savings of HBM traffic on top of the first version:
+//  * straight-sided elements (CurvedParams::affineEl; decided per tile with one ballot): W rx, W ry, W sx, W sy at the Ncub
+//    points are 4 numbers per element times the rule's weights, so the four Ncub-row planes are not read for them;
+//  * the element's own Gauss traces are formed here by the tile products of the Gauss kernel (same instructions, same
+//    operands: bit-identical to what the neighbours read from gq) instead of being read back.
+// MAPM: gmapM is not the identity (the interior traces are gathered through it like the exterior ones).
+template <int N, int MODE, bool FILTER, bool OPSLDS, int FB, int WAVES, bool MAPM = false>
 __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const CurvedParams p) {
     using O = CurvedOps<N>;
     constexpr int Np = O::Np, KV = O::KV, MT = O::MT;
@@ -231,9 +259,9 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
     const int ncb = p.ncb;
     constexpr int fb = FB;
     const int offDrT = O::offDrT(ncb, fb), offDsT = O::offDsT(ncb, fb), offIT = O::offIT(ncb, fb),
-              offMass = FILTER ? O::offMF(ncb, fb) : O::offM(ncb, fb), offF = O::offF(ncb, fb);
+              offMass = FILTER ? O::offMF(ncb, fb) : O::offM(ncb, fb), offF = O::offF(ncb, fb), offGI = O::offGI(ncb, fb);
     if constexpr (OPSLDS) {
-        const int n = O::offGI(ncb, fb) * 64;
+        const int n = O::tiles(ncb, fb) * 64;
         for (int t = threadIdx.x; t < n; t += blockDim.x) sOps[t] = p.ops[t];
         __syncthreads();
     }
@@ -245,6 +273,27 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 
     const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, gplane = 48ll * fb * ld,
                     cplane = 16ll * ncb * ld;
+    const unsigned ld8 = static_cast<unsigned>(ld) * 8u, ld4 = static_cast<unsigned>(ld) * 4u;
+    const unsigned planeB = static_cast<unsigned>(plane * 8), gplaneB = static_cast<unsigned>(gplane * 8),
+                   cplaneB = static_cast<unsigned>(cplane * 8);
+    __amdgpu_buffer_rsrc_t rq[4], rold[4], rout[4], rres[4], rgq[4], rcub[4], rgg[3];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        rq[c] = cplane_rsrc(p.qin + c * plane, planeB);
+        rold[c] = cplane_rsrc((MODE == CMODE_LSERK ? p.res : (MODE == CMODE_COMBINE ? p.qbase : p.qin)) + c * plane, planeB);
+        rout[c] = cplane_rsrc((MODE == CMODE_RHS ? p.rhs : p.qout) + c * plane, planeB);
+        rres[c] = cplane_rsrc((MODE == CMODE_LSERK ? p.res : p.qin) + c * plane, planeB);
+        rgq[c] = cplane_rsrc(p.gq + c * gplane, gplaneB);
+        rcub[c] = cplane_rsrc(p.cubG + c * cplane, cplaneB);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rgg[i] = cplane_rsrc(p.gaussG + i * gplane, gplaneB);
+    const __amdgpu_buffer_rsrc_t rmapP = cplane_rsrc(p.gmapP, static_cast<unsigned>(gplane * 4)),
+                                 rmapM = cplane_rsrc(p.gmapM ? p.gmapM : p.gmapP, static_cast<unsigned>(gplane * 4)),
+                                 rrJ = cplane_rsrc(p.rJ, planeB), rzx = cplane_rsrc(p.zx ? p.zx : p.rJ, planeB),
+                                 rzy = cplane_rsrc(p.zy ? p.zy : p.rJ, planeB), rfc = cplane_rsrc(p.fcor ? p.fcor : p.rJ, planeB),
+                                 rcd = cplane_rsrc(p.cd ? p.cd : p.rJ, planeB),
+                                 raff = cplane_rsrc(p.cubAffine ? p.cubAffine : p.rJ, 4u * ld8);
     const double g = p.g;
     const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u;
     unsigned tile, tileEnd;
@@ -253,17 +302,42 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
         const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
         const bool live = kTrue <= kLast;
         const unsigned k = live ? kTrue : kLast; // padding lanes recompute the last element, store nothing
-        const unsigned k8 = k * 8u, k4 = k * 4u;
+        const unsigned k8 = k * 8u, k4 = k * 4u, v8 = (q * static_cast<unsigned>(ld) + k) * 8u, v4 = v8 >> 1;
+        // vector offset of node row 4 t + q (out of range on the padding rows of the last k-step)
+        auto nodeOff = [&](int t) -> unsigned {
+            if constexpr (Np % 4 != 0) {
+                if (t == KV - 1) return (4 * (KV - 1) + static_cast<int>(q) < Np) ? v8 : 0xfffffff8u;
+            }
+            return v8;
+        };
 
-        // ---- own nodal state in operand layout: node m = 4 t + q
+        // ---- own nodal state in operand layout: node m = 4 t + q (0 on padding rows)
         double qB[4][KV];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int t = 0; t < KV; ++t) {
-                const int m = 4 * t + static_cast<int>(q);
-                qB[c][t] = m < Np ? cld_row(p.qin + c * plane + m * ld, k8) : 0.0;
+            for (int t = 0; t < KV; ++t) qB[c][t] = cbld_f64(rq[c], nodeOff(t), static_cast<unsigned>(4 * t) * ld8);
+        // straight-sided tile? (one ballot; padding lanes repeat the last element)
+        bool affTile = false;
+        double ca[4] = {0.0, 0.0, 0.0, 0.0};
+        if (p.cubAffine) {
+            affTile = __all(p.affineEl[k] != 0);
+            if (affTile) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ca[i] = cbld_f64(raff, k8, static_cast<unsigned>(i) * ld8);
             }
+        }
+
+        // exterior-trace indices of all three faces, requested before the volume term: each face then has one dependent
+        // memory round trip (the gathers), not two
+        int idxP[3][FB][4];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int b = 0; b < FB; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    idxP[f][b][reg] = cbld_i32(rmapP, v4, static_cast<unsigned>(16 * (f * FB + b) + 4 * reg) * ld4);
 
         cmfma_t acc[4][MT];
 #pragma unroll
@@ -285,9 +359,15 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) { // 4 cubature points of this lane = contraction step reg of DrT / DsT
                 const int row = 16 * rb + static_cast<int>(q) + 4 * reg;
-                const long long ro = static_cast<long long>(row) * ld;
-                const double wrx = cld_row(p.cubG + ro, k8), wry = cld_row(p.cubG + cplane + ro, k8),
-                             wsx = cld_row(p.cubG + 2 * cplane + ro, k8), wsy = cld_row(p.cubG + 3 * cplane + ro, k8);
+                const unsigned so = static_cast<unsigned>(16 * rb + 4 * reg) * ld8;
+                double wrx, wry, wsx, wsy;
+                if (affTile) { // rule weight (times a reference Jacobian) of this point, the element's four numbers
+                    const double w = p.cubWref[row]; // zero on padding rows
+                    wrx = w * ca[0]; wry = w * ca[1]; wsx = w * ca[2]; wsy = w * ca[3];
+                } else {
+                    wrx = cbld_f64(rcub[0], v8, so); wry = cbld_f64(rcub[1], v8, so);
+                    wsx = cbld_f64(rcub[2], v8, so); wsy = cbld_f64(rcub[3], v8, so);
+                }
                 const bool valid = row < p.ncub;
                 const CurvedFlux fl = curved_fluxes(valid ? cv[0][reg] : 1.0, cv[1][reg], cv[2][reg], cv[3][reg], g);
                 double tr[4], ts[4];
@@ -310,28 +390,46 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 
         // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face. One pass: the
         //      weighted central flux and jump of every point stay in registers until the face's speed is known.
-#pragma unroll 1
+        //      (Requesting face f + 1's traces and geometry while face f is worked on was tried: +66 spilled VGPRs at two
+        //      waves per SIMD, 0.61 -> 0.67 ms per evaluation; not kept.)
+#pragma unroll
         for (int f = 0; f < 3; ++f) {
             double lam = 0.0;
             double ef[FB][4][4], dj[FB][4][4];
 #pragma unroll
             for (int b = 0; b < FB; ++b) {
                 const int gb = f * FB + b;
+                // the element's own traces at this block's 16 Gauss rows: the Gauss kernel's products (identity gmapM)
+                cmfma_t gM[4];
+                if constexpr (!MAPM) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gM[c] = cmfma_zero();
+#pragma unroll
+                    for (int t = 0; t < KV; ++t) {
+                        const double a = A(offGI + gb * KV + t);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], gM[c], 0, 0, 0);
+                    }
+                }
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
-                    const int local = 16 * b + static_cast<int>(q) + 4 * reg, gr = 16 * gb + static_cast<int>(q) + 4 * reg;
+                    const int local = 16 * b + static_cast<int>(q) + 4 * reg;
                     const bool valid = local < p.ng;
-                    const long long go = static_cast<long long>(gr) * ld;
-                    const int idP = cld_row(p.gmapP + go, k4);
+                    const unsigned so8 = static_cast<unsigned>(16 * gb + 4 * reg) * ld8, so4 = static_cast<unsigned>(16 * gb + 4 * reg) * ld4;
+                    const int idP = idxP[f][b][reg];
                     const unsigned oP = static_cast<unsigned>(idP < 0 ? -(idP + 1) : idP) * 8u;
-                    const unsigned oM = p.gmapM ? static_cast<unsigned>(cld_row(p.gmapM + go, k4)) * 8u
-                                                : static_cast<unsigned>(go) * 8u + k8;
-                    double hM = cld_row(p.gq, oM), huM = cld_row(p.gq + gplane, oM), hvM = cld_row(p.gq + 2 * gplane, oM),
-                           hNM = cld_row(p.gq + 3 * gplane, oM);
-                    double hP = cld_row(p.gq, oP), huP = cld_row(p.gq + gplane, oP), hvP = cld_row(p.gq + 2 * gplane, oP),
-                           hNP = cld_row(p.gq + 3 * gplane, oP);
-                    const double nx = cld_row(p.gaussG + go, k8), ny = cld_row(p.gaussG + gplane + go, k8),
-                                 hW = 0.5 * cld_row(p.gaussG + 2 * gplane + go, k8); // zero on padding rows
+                    double hM, huM, hvM, hNM;
+                    if constexpr (MAPM) {
+                        const unsigned oM = static_cast<unsigned>(cbld_i32(rmapM, v4, so4)) * 8u;
+                        hM = cbld_f64(rgq[0], oM, 0u); huM = cbld_f64(rgq[1], oM, 0u);
+                        hvM = cbld_f64(rgq[2], oM, 0u); hNM = cbld_f64(rgq[3], oM, 0u);
+                    } else {
+                        hM = gM[0][reg]; huM = gM[1][reg]; hvM = gM[2][reg]; hNM = gM[3][reg];
+                    }
+                    double hP = cbld_f64(rgq[0], oP, 0u), huP = cbld_f64(rgq[1], oP, 0u), hvP = cbld_f64(rgq[2], oP, 0u),
+                           hNP = cbld_f64(rgq[3], oP, 0u);
+                    const double nx = cbld_f64(rgg[0], v8, so8), ny = cbld_f64(rgg[1], v8, so8),
+                                 hW = 0.5 * cbld_f64(rgg[2], v8, so8); // zero on padding rows
                     if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
                     const double rM = crcp(hM), rP = crcp(hP);
                     // the wave speeds use the exterior velocity BEFORE the wall condition (rhs.py:81-85, :93-94)
@@ -375,7 +473,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
         }
 
         // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
-        const int slot = p.curvedSlot ? cld_row(p.curvedSlot, k4) : -1;
+        const int slot = p.curvedSlot ? p.curvedSlot[k] : -1;
         cmfma_t out[4][MT];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
@@ -385,11 +483,17 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 #pragma unroll
         for (int t = 0; t < KV; ++t) {
             const int m = 4 * t + static_cast<int>(q);
-            S2[t] = S3[t] = 0.0;
-            double rj = 0.0;
-            if (m < Np) {
-                rj = cld_row(p.rJ + m * ld, k8);
-                curved_sources(p, qB[0][t], qB[1][t], qB[2][t], m * ld, k8, S2[t], S3[t]);
+            const unsigned so = static_cast<unsigned>(4 * t) * ld8, vo = nodeOff(t);
+            const double rj = cbld_f64(rrJ, vo, so); // 0 on padding rows
+            {   // momentum sources at the node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx, S3 = -(f hu - CD |u| v) - g h zy
+                const double h = m < Np ? qB[0][t] : 1.0, hu = qB[1][t], hv = qB[2][t];
+                const double rh = crcp(h);
+                const double u = hu * rh, v = hv * rh;
+                const double fco = p.fcor ? cbld_f64(rfc, vo, so) : p.fconst, cdv = p.cd ? cbld_f64(rcd, vo, so) : p.cdconst;
+                const double cdn = cdv * csqrt(u * u + v * v);
+                const double zx = p.zx ? cbld_f64(rzx, vo, so) : 0.0, zy = p.zy ? cbld_f64(rzy, vo, so) : 0.0;
+                S2[t] = m < Np ? (fco * hv - cdn * u) - g * h * zx : 0.0;
+                S3[t] = m < Np ? -(fco * hu - cdn * v) - g * h * zy : 0.0;
             }
 #pragma unroll
             for (int r = 0; r < MT; ++r) {
@@ -417,15 +521,15 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
                     }
                     double R = out[c][t >> 2][t & 3];
                     if constexpr (!FILTER) R += c == 1 ? S2[t] : (c == 2 ? S3[t] : 0.0);
-                    const long long off = c * plane + m * ld;
+                    const unsigned so = static_cast<unsigned>(4 * t) * ld8;
                     if constexpr (MODE == CMODE_RHS) {
-                        cst_row(p.rhs + off, k8, R);
+                        cbst_f64(rout[c], v8, so, R);
                     } else if constexpr (MODE == CMODE_LSERK) {
-                        const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * R;
-                        cst_row(p.res + off, k8, n1);
-                        cst_row(p.qout + off, k8, qB[c][t] + p.cb * n1);
+                        const double n1 = p.ca * cbld_f64(rold[c], v8, so) + p.cc * R;
+                        cbst_f64(rres[c], v8, so, n1);
+                        cbst_f64(rout[c], v8, so, qB[c][t] + p.cb * n1);
                     } else {
-                        cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * qB[c][t] + p.cc * R);
+                        cbst_f64(rout[c], v8, so, p.ca * cbld_f64(rold[c], v8, so) + p.cb * qB[c][t] + p.cc * R);
                     }
                 }
         }

@@ -15,12 +15,12 @@ using O = CurvedOps<kN>;
 // Dynamic LDS a workgroup of the stage kernel may claim for the operator image; beyond it the tiles are read
 // from global memory (they stay in L1 / L2: every wave reads the same image).
 constexpr int kLdsBudgetBytes = 150 * 1024;
-// measured (profiles/r02_curved_*): N=4 0.74 ms at 2 waves (118 spilled VGPRs) against 0.84 ms at 1; N=6 1.82 against
-// 1.42 ms; N=8 3.11 against 3.34 ms
-constexpr int kDefaultWaves = (BDG_ORDER <= 4 || BDG_ORDER >= 8) ? 2 : 1;
+// measured per evaluation (profiles/r02_curved_timings.json), 2 waves per SIMD against 1: N=3 0.46 / 0.61 ms, N=4 0.54 /
+// 0.70, N=5 0.84 / 0.74, N=6 0.88 / 0.73, N=8 1.86 / 1.76
+constexpr int kDefaultWaves = BDG_ORDER <= 4 ? 2 : 1;
 
 int opsTiles(int ncb, int fb) { return O::tiles(ncb, fb); }
-int stageTiles(int ncb, int fb) { return O::offGI(ncb, fb); }
+int stageTiles(int ncb, int fb) { return O::tiles(ncb, fb); }
 void opsOffsets(int ncb, int fb, int* off) {
     off[0] = O::offVc(ncb, fb); off[1] = O::offDrT(ncb, fb); off[2] = O::offDsT(ncb, fb); off[3] = O::offIT(ncb, fb);
     off[4] = O::offM(ncb, fb); off[5] = O::offMF(ncb, fb); off[6] = O::offF(ncb, fb); off[7] = O::offGI(ncb, fb);
@@ -38,7 +38,7 @@ hipError_t gauss(const CurvedParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int MODE, bool FILTER, int FB, int WAVES>
+template <int MODE, bool FILTER, int FB, int WAVES, bool MAPM = false>
 hipError_t launchStageFb(const CurvedParams& p, hipStream_t stream);
 
 // Register budget: BDG_SW2D_CURVED_WAVES = 1 | 2 waves per SIMD (A/B switch; default below).
@@ -53,17 +53,22 @@ int curvedWaves() {
 template <int MODE, bool FILTER>
 hipError_t launchStage(const CurvedParams& p, hipStream_t stream) {
     const bool two = curvedWaves() == 2;
+    if (p.gmapM) { // rewired interior map (rare): one register budget only
+        if (p.fb == 1) return launchStageFb<MODE, FILTER, 1, 1, true>(p, stream);
+        if (p.fb == 2) return launchStageFb<MODE, FILTER, 2, 1, true>(p, stream);
+        return hipErrorInvalidValue;
+    }
     if (p.fb == 1) return two ? launchStageFb<MODE, FILTER, 1, 2>(p, stream) : launchStageFb<MODE, FILTER, 1, 1>(p, stream);
     if (p.fb == 2) return two ? launchStageFb<MODE, FILTER, 2, 2>(p, stream) : launchStageFb<MODE, FILTER, 2, 1>(p, stream);
     return hipErrorInvalidValue; // more than 32 Gauss points per face: refused at creation
 }
 
-template <int MODE, bool FILTER, int FB, int WAVES>
+template <int MODE, bool FILTER, int FB, int WAVES, bool MAPM>
 hipError_t launchStageFb(const CurvedParams& p, hipStream_t stream) {
     if (p.K < 1) return hipSuccess;
-    const size_t lds = static_cast<size_t>(O::offGI(p.ncb, p.fb)) * 64 * sizeof(double);
+    const size_t lds = static_cast<size_t>(O::tiles(p.ncb, p.fb)) * 64 * sizeof(double);
     if (lds <= static_cast<size_t>(kLdsBudgetBytes)) {
-        auto kern = sw2d_curved_stage_kernel<kN, MODE, FILTER, true, FB, WAVES>;
+        auto kern = sw2d_curved_stage_kernel<kN, MODE, FILTER, true, FB, WAVES, MAPM>;
         if (lds > 64 * 1024) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
@@ -72,7 +77,7 @@ hipError_t launchStageFb(const CurvedParams& p, hipStream_t stream) {
         const int wgPerCu = std::max(1, static_cast<int>(160 * 1024 / std::max<size_t>(lds, 1)));
         hipLaunchKernelGGL(kern, dim3(gridFor(p.K, std::min(wgPerCu, 2))), dim3(256), lds, stream, p);
     } else {
-        hipLaunchKernelGGL((sw2d_curved_stage_kernel<kN, MODE, FILTER, false, FB, WAVES>), dim3(gridFor(p.K, 2)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((sw2d_curved_stage_kernel<kN, MODE, FILTER, false, FB, WAVES, MAPM>), dim3(gridFor(p.K, 2)), dim3(256), 0, stream, p);
     }
     return hipGetLastError();
 }
