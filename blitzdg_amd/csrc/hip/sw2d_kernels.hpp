@@ -83,6 +83,9 @@ struct StageParams {
     // workgroups (0: one per CU). Interior launches of a partitioned run leave a few CUs to the partition-boundary
     // kernel on the exchange stream, which could not start beside 256 LDS-filling workgroups otherwise.
     int gridCap;
+    // sw2d_stage_mfma3_kernel: 1 = the waves of an XCD take tiles side by side (stride = waves per XCD) instead of one
+    // contiguous chunk of tiles per wave
+    int tileInterleave;
 };
 
 // Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):

@@ -108,8 +108,17 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
     const unsigned wave = blk * 4u + (threadIdx.x >> 6), nwaves = nwg * 4u;
     const unsigned ntiles = (static_cast<unsigned>(p.kend - p.kbegin) + 15u) / 16u;
     const unsigned perWave = (ntiles + nwaves - 1u) / nwaves;
-    const unsigned tileEnd = min(ntiles, (wave + 1u) * perWave);
+    unsigned tileEnd = min(ntiles, (wave + 1u) * perWave), tileStep = 1u;
     unsigned tile = wave * perWave;
+    if (p.tileInterleave) {
+        // the waves of one XCD walk its share of the tiles side by side: at any time the XCD works on one compact
+        // patch of the mesh, whose interior face neighbours are in its L2 because a sibling wave is reading them
+        // (its share of the tiles is proportional to its share of the workgroups: none if it has none)
+        const unsigned wgHere = (nwg + 7u - xcd) / 8u, wgBefore = blk - blockIdx.x / 8u;
+        tile = ntiles * wgBefore / nwg + (blockIdx.x / 8u) * 4u + (threadIdx.x >> 6);
+        tileEnd = ntiles * (wgBefore + wgHere) / nwg;
+        tileStep = wgHere * 4u;
+    }
     if (tile >= tileEnd) return;
 
     const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
@@ -222,9 +231,9 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
 #pragma unroll 1
     for (;;) {
         const unsigned v8 = (q * static_cast<unsigned>(ld) + k) * 8u;
-        const bool more = tile + 1u < tileEnd;
+        const bool more = tile + tileStep < tileEnd;
         bool liveN = false;
-        const unsigned kN = more ? elementOf(tile + 1u, liveN) : k;
+        const unsigned kN = more ? elementOf(tile + tileStep, liveN) : k;
         // next tile, requested piece by piece below as this tile's registers fall free
         double qN[3][KV], geoN[13], hPN[3][KF], huPN[3][KF], hvPN[3][KF];
         int fidxN[3][KF];
@@ -478,7 +487,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                 }
         }
         if (!more) break;
-        ++tile;
+        tile += tileStep;
         k = kN;
         live = liveN;
 #pragma unroll

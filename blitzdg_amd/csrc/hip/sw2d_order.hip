@@ -239,7 +239,10 @@ hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
     const unsigned cap = p.gridCap > 0 ? static_cast<unsigned>(p.gridCap) : 256u;
     const unsigned grid = std::min((ntiles + 3u) / 4u, cap); // one four-wave workgroup per CU, one wave per SIMD
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, p);
+    static const int interleave = [] { const char* e = std::getenv("BDG_SW2D_TILE_INTERLEAVE"); return e ? std::atoi(e) : 1; }();
+    StageParams pi = p;
+    pi.tileInterleave = interleave;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
     return hipGetLastError();
 }
 
