@@ -11,7 +11,8 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libblitzdg_hip.so")
+# BDG_HIP_LIBRARY: another build of the same library (profiling builds under build/); there is still no fallback
+LIB_PATH = os.environ.get("BDG_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libblitzdg_hip.so")
 
 BDG_OK, BDG_ERR_ARGUMENT, BDG_ERR_RUNTIME, BDG_ERR_HIP, BDG_ERR_UNSTABLE = 0, 1, 2, 3, 4
 BDG_F64, BDG_I32 = 0, 1

@@ -86,6 +86,10 @@ struct StageParams {
     // sw2d_stage_mfma3_kernel: 1 = the waves of an XCD take tiles side by side (stride = waves per XCD) instead of one
     // contiguous chunk of tiles per wave
     int tileInterleave;
+    // sw2d_stage_mfma3_kernel: workgroups start (blk mod 8) * stagger kilocycles apart (0: together)
+    int stagger;
+    // profiling builds (-DBDG_PHASE_CLOCK): 16 cycle counts per wave (LDS copy, k-steps, surface, update), else unused
+    unsigned long long* phaseClock;
 };
 
 // Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):

@@ -11,10 +11,19 @@
 // instead of by a second wave: the next tile's state and gather indices, this tile's neighbour traces and residual
 // are all requested well before their first use, in batches pinned with scheduling barriers.
 //   per tile:  LDS copy  ->  volume k-step t  [pointwise work of one face node; next tile: state row t, traces of a
-//              finished face]  ->  [residual rows, next tile: geometry]  ->  faces (matrix instructions only)
-//              ->  update (own state back from the LDS copy) + stores
+//              finished face; this tile: residual rows]  ->  [next tile: geometry]  ->  for each block of 16 output rows:
+//              the faces' matrix instructions, then the block's update (own state back from the LDS copy) + stores
 // A register that held a state row (a face's neighbour traces) is free once that k-step's (face's) operands exist, so
 // the next tile's copy of it is requested right there and nothing of a tile is waited for at its start.
+//
+// What the schedule has to respect on gfx950 (measured: profiles/microbench/mfma_valu_overlap.hip, profiles/README.md):
+//  * v_mfma_f64_16x16x4_f64 occupies the SIMD's vector ALU for its 64 cycles: no vector instruction of this wave or of
+//    any other wave on the SIMD runs beside it, so there is nothing to gain from interleaving vector work with matrix
+//    instructions; what counts is the total of the two and that memory instructions keep flowing between them.
+//  * A wave has at most 63 vector-memory instructions in flight (vmcnt) and a tile issues about 190 (N=8): requests are
+//    spread over the tile -- a burst (all residual rows at once, all 6 KV stores at once) stalls on acknowledgements.
+//  * A spilled register is reloaded with a scratch load followed by s_waitcnt vmcnt(0), which drains every prefetch in
+//    flight: the straight-sided forms are kept free of spills at every order (tests/test_isa_hazards.py).
 // Same operator image (MfmaOps2) and the same arithmetic as sw2d_stage_mfma2_kernel<N, MODE, 0>.
 #pragma once
 #include "sw2d_mfma_kernel.hpp"
@@ -211,6 +220,24 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         }
     };
 
+#ifdef BDG_PHASE_CLOCK
+    // profiling build only (-DBDG_PHASE_CLOCK): cycles a wave spends in each phase of a tile, summed over its tiles
+    unsigned long long phase[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp = 0;
+#define BDG_STAMP(i)                                                          \
+    {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const unsigned long long now = __builtin_readcyclecounter();          \
+        phase[i] += now - stamp;                                              \
+        stamp = now;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    }
+#else
+#define BDG_STAMP(i)
+#endif
+    if (p.stagger > 0) { // workgroups start out of phase: (blk mod 8) * stagger kilocycles apart
+        const unsigned naps = (blk & 7u) * static_cast<unsigned>(p.stagger);
+        for (unsigned i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     bool live;
     unsigned k = elementOf(tile, live);
     double qB[3][KV], geo[13], hP[3][KF], huP[3][KF], hvP[3][KF];
@@ -228,6 +255,9 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         for (int f = 0; f < 3; ++f) loadFaceGeometry(f, k, fnx, fny, fsc);
     }
 
+#ifdef BDG_PHASE_CLOCK
+    stamp = __builtin_readcyclecounter();
+#endif
 #pragma unroll 1
     for (;;) {
         const unsigned v8 = (q * static_cast<unsigned>(ld) + k) * 8u;
@@ -249,15 +279,24 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             }
         __builtin_amdgcn_wave_barrier(); // other lanes of this wave read these values back (DS operations of a wave execute in order)
 
+        BDG_STAMP(0) // LDS copy
+        // residual (LSERK) / base state (COMBINE) rows of THIS tile: requested during the first volume k-steps, consumed
+        // by the update of their row block
+        double oldv[3][KV];
+        auto loadOldRow = [&](int t) {
+            if constexpr (MODE != MODE_RHS) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) oldv[c][t] = bld_f64(rold[c], row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
+            }
+        };
         mfma_acc_t acc[3][MT];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int r = 0; r < MT; ++r) acc[c][r] = mfma_zero(); // not a literal 0: see mfma_zero
 
-        // volume term, software pipelined by hand: the six operands of k-step t + 1 are formed (vector ALU) in the same
-        // scheduling region as the 6 MT matrix instructions of k-step t, so the two pipes overlap within one wave; the
-        // state rows of k-step t are dead by then and the same rows of the NEXT tile are requested in their place
+        // volume term: the six operands of k-step t (vector ALU), then its 6 MT matrix instructions; the state rows of
+        // k-step t are dead by then and the same rows of the NEXT tile are requested in their place
         auto volumeOperands = [&](int t, double (&ab)[6]) {
             const int m = 4 * t + static_cast<int>(q);
             const bool pad = m >= Np;
@@ -278,9 +317,9 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             }
         };
         // Pointwise work of the surface term (face node n = 4 tf + q of face f; '-' traces from the LDS tile, '+' traces
-        // prefetched during the previous tile), one face node per lane at a time: it is spread over the volume k-steps,
-        // whose matrix instructions leave the vector ALU mostly idle, so that the faces' own matrix instructions later
-        // run back to back. A face's operands s_c = Fscale/2 (e_c - lam d_c) are final once its last node is in.
+        // prefetched during the previous tile), one face node per lane at a time: it is spread over the volume k-steps so
+        // that a face's neighbour-trace registers fall free early and the next tile's gathers go out one face at a time.
+        // A face's operands s_c = Fscale/2 (e_c - lam d_c) are final once its last node is in.
         double sF[3][3][KF];
         double eF[3][KF], dF[3][KF], lamF = 0.0;
         auto faceNode = [&](int f, int tf) {
@@ -321,21 +360,26 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                     for (int c = 0; c < 3; ++c) sF[f][c][t2] = hfs * (eF[c][t2] - lam * dF[c][t2]);
                 }
                 lamF = 0.0;
-                loadTraces(f, fidxN, hPN, huPN, hvPN); // this face's '+' traces are dead: request the next tile's
+                // this face's '+' traces are dead: request the next tile's (requesting all three faces in the last k-steps
+                // instead, so that they never wait for their indices, was slower: too many requests at once)
+                loadTraces(f, fidxN, hPN, huPN, hvPN);
                 if constexpr (NODAL) loadFaceGeometry(f, kN, fnxN, fnyN, fscN);
             }
         };
         constexpr int FACE_ITEMS = 3 * KF, PER_STEP = (FACE_ITEMS + KV - 1) / KV;
 
         if constexpr (!NODAL) {
-            double abCur[6], abNext[6];
-            volumeOperands(0, abCur);
             loadIndices(kN, fidxN);
             __builtin_amdgcn_sched_barrier(0);
+            // residual rows: blocks 0 .. MT - 2 during the last k-steps (one row per step), the last block at the start of
+            // the surface term -- each a good microsecond before its update, and no earlier (registers)
+            constexpr int OLD_EARLY = HALO ? 0 : ((MT > 1 ? 4 * (MT - 1) : 0) < KV ? (MT > 1 ? 4 * (MT - 1) : 0) : KV); // (HALO: registers)
 #pragma unroll
             for (int t = 0; t < KV; ++t) {
-                if (t + 1 < KV) volumeOperands(t + 1, abNext);
+                double ab[6];
+                volumeOperands(t, ab);
                 loadStateRow(kN, t, qN);
+                if (t >= KV - OLD_EARLY) loadOldRow(t - (KV - OLD_EARLY));
 #pragma unroll
                 for (int it = t * PER_STEP; it < (t + 1) * PER_STEP; ++it)
                     if (it < FACE_ITEMS) faceNode(it / KF, it % KF);
@@ -343,17 +387,18 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                 for (int r2 = 0; r2 < MT; ++r2) {
                     const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
                     const double Ads = sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane];
-                    acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[0], acc[0][r2], 0, 0, 0);
-                    acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[2], acc[1][r2], 0, 0, 0);
-                    acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, abCur[4], acc[2][r2], 0, 0, 0);
-                    acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[1], acc[0][r2], 0, 0, 0);
-                    acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[3], acc[1][r2], 0, 0, 0);
-                    acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, abCur[5], acc[2][r2], 0, 0, 0);
+                    acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, ab[0], acc[0][r2], 0, 0, 0);
+                    acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, ab[2], acc[1][r2], 0, 0, 0);
+                    acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, ab[4], acc[2][r2], 0, 0, 0);
+                    acc[0][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, ab[1], acc[0][r2], 0, 0, 0);
+                    acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, ab[3], acc[1][r2], 0, 0, 0);
+                    acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, ab[5], acc[2][r2], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) abCur[i] = abNext[i];
+                BDG_STAMP(1 + (t < 12 ? t : 11)) // k-step t
             }
+#pragma unroll
+            for (int t = OLD_EARLY; t < KV; ++t) loadOldRow(t);
         } else {
             // One 16-row block of output nodes at a time: av[2 i] = Dr s_i, av[2 i + 1] = Ds s_i for the five flux functions
             // s = (hu, hv, F2, G2, G3) (their values are formed again in every pass: a few dozen vector instructions against
@@ -399,32 +444,112 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                     }
                 }
             }
+#pragma unroll
+            for (int t = 0; t < KV; ++t) loadOldRow(t); // (registers: not before the last pass is over)
         }
 
-        // ---- residual (LSERK) / base state (COMBINE) rows of this tile, consumed by the update after the faces
-        double oldv[3][KV];
-        if constexpr (MODE != MODE_RHS) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int t = 0; t < KV; ++t) oldv[c][t] = bld_f64(rold[c], row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
-        }
+        BDG_STAMP(13) // volume term (rest)
         loadGeometry(kN, geoN);
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---- surface term: matrix instructions only (operands formed above)
-#pragma unroll
-        for (int f = 0; f < 3; ++f)
-#pragma unroll
-            for (int tf = 0; tf < KF; ++tf)
-#pragma unroll
-                for (int r = 0; r < MT; ++r) {
-                    const double Al = sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane];
-                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][0][tf], acc[0][r], 0, 0, 0);
-                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][1][tf], acc[1][r], 0, 0, 0);
-                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][2][tf], acc[2][r], 0, 0, 0);
+        // ---- stage update / output of the rows of block r: node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3);
+        //      stores of the padding rows carry an out-of-range vector offset (row_voffset) and are dropped, padding lanes
+        //      store nothing. The block's own state comes back from the LDS tile in one batch.
+        int sendRec[3] = {-1, -1, -1};
+        auto loadSendRecords = [&]() { // (HALO) right before the update: nothing of it lives across the surface term
+            if constexpr (HALO) {
+                if (live) {
+                    const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
+                    sendRec[0] = p.haloSendOf[b3];
+                    sendRec[1] = p.haloSendOf[b3 + 1];
+                    sendRec[2] = p.haloSendOf[b3 + 2];
                 }
-        __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        auto updateBlock = [&](int r) {
+            if (!live) return;
+            double own[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = 4 * (4 * r + e) + static_cast<int>(q);
+                    own[c][e] = (4 * r + e < KV && m < Np) ? sOps[sBase + (c * Np + m) * 16] : 0.0;
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int t = 4 * r + e;
+                    if (t >= KV) continue;
+                    const int m = 4 * t + static_cast<int>(q);
+                    const unsigned soff = static_cast<unsigned>(4 * t) * ld8;
+                    const double R = acc[c][r][e];
+                    if constexpr (MODE == MODE_RHS) {
+                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, R);
+                    } else if constexpr (MODE == MODE_LSERK) {
+                        const double n1 = p.ca * oldv[c][t] + p.cc * R;
+                        const double qn = own[c][e] + p.cb * n1;
+                        bst_f64(rres[c], row_voffset<Np, KV>(t, q, v8), soff, n1);
+                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, qn);
+                        if constexpr (HALO) {
+                            if (m < Np) {
+#pragma unroll
+                                for (int sr = 0; sr < 3; ++sr)
+                                    if (sendRec[sr] >= 0)
+                                        p.haloSend[static_cast<size_t>(sendRec[sr]) * p.haloRows + c * Np + m] = qn;
+                            }
+                        }
+                    } else {
+                        const double val = p.ca * oldv[c][t] + p.cb * own[c][e] + p.cc * R;
+                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, c == 0 ? val : sponge_relax(val, p.sponge));
+                    }
+                }
+        };
+
+        // ---- surface term: matrix instructions only (operands formed above). Straight-sided single-domain form: one
+        //      block of 16 output rows at a time, so that a block's rows are updated and stored while the next block's
+        //      products run and the stores of a tile are spread over the phase instead of arriving as one burst of 6 KV (a
+        //      wave has at most 63 memory instructions in flight: the burst stalls on the first ones' acknowledgements).
+        //      The other forms have no registers for it (a face's operands stay live until the last block): face by face,
+        //      update at the end.
+        constexpr bool BLOCKWISE = !NODAL && !HALO;
+        if constexpr (BLOCKWISE) {
+#pragma unroll
+            for (int r = 0; r < MT; ++r) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f)
+#pragma unroll
+                    for (int tf = 0; tf < KF; ++tf) {
+                        const double Al = sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane];
+                        acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][0][tf], acc[0][r], 0, 0, 0);
+                        acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][1][tf], acc[1][r], 0, 0, 0);
+                        acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][2][tf], acc[2][r], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                updateBlock(r);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int tf = 0; tf < KF; ++tf)
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        const double Al = sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane];
+                        acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][0][tf], acc[0][r], 0, 0, 0);
+                        acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][1][tf], acc[1][r], 0, 0, 0);
+                        acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, sF[f][2][tf], acc[2][r], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!NFILT) {
+                loadSendRecords();
+#pragma unroll
+                for (int r = 0; r < MT; ++r) updateBlock(r);
+            }
+        }
+        BDG_STAMP(14) // surface term
 
         if constexpr (NFILT) { // RHS <- Filter * RHS: the accumulators are the operands of one more product
             mfma_acc_t fo[3][MT];
@@ -445,47 +570,10 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int r = 0; r < MT; ++r) acc[c][r] = fo[c][r];
+#pragma unroll
+            for (int r = 0; r < MT; ++r) updateBlock(r);
         }
-
-        // ---- stage update / output: node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3); stores of the
-        //      padding rows carry an out-of-range vector offset (row_voffset) and are dropped, padding lanes store nothing
-        if (live) {
-            int sendRec[3] = {-1, -1, -1};
-            if constexpr (HALO) {
-                const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
-                sendRec[0] = p.haloSendOf[b3];
-                sendRec[1] = p.haloSendOf[b3 + 1];
-                sendRec[2] = p.haloSendOf[b3 + 2];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-#pragma unroll
-                for (int t = 0; t < KV; ++t) {
-                    const int m = 4 * t + static_cast<int>(q);
-                    const unsigned soff = static_cast<unsigned>(4 * t) * ld8;
-                    const double R = acc[c][t >> 2][t & 3];
-                    const double own = m < Np ? sOps[sBase + (c * Np + m) * 16] : 0.0;
-                    if constexpr (MODE == MODE_RHS) {
-                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, R);
-                    } else if constexpr (MODE == MODE_LSERK) {
-                        const double n1 = p.ca * oldv[c][t] + p.cc * R;
-                        const double qn = own + p.cb * n1;
-                        bst_f64(rres[c], row_voffset<Np, KV>(t, q, v8), soff, n1);
-                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, qn);
-                        if constexpr (HALO) {
-                            if (m < Np) {
-#pragma unroll
-                                for (int sr = 0; sr < 3; ++sr)
-                                    if (sendRec[sr] >= 0)
-                                        p.haloSend[static_cast<size_t>(sendRec[sr]) * p.haloRows + c * Np + m] = qn;
-                            }
-                        }
-                    } else {
-                        const double val = p.ca * oldv[c][t] + p.cb * own + p.cc * R;
-                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, c == 0 ? val : sponge_relax(val, p.sponge));
-                    }
-                }
-        }
+        BDG_STAMP(15) // update and stores
         if (!more) break;
         tile += tileStep;
         k = kN;
@@ -506,6 +594,13 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             }
 
     }
+#ifdef BDG_PHASE_CLOCK
+    if (p.phaseClock != nullptr && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) p.phaseClock[(blockIdx.x * 4u + (threadIdx.x >> 6)) * 16u + i] = phase[i];
+    }
+#endif
+#undef BDG_STAMP
 }
 
 } // namespace bdg_dev

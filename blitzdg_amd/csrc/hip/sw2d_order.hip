@@ -1,7 +1,10 @@
 // Instantiates the sw2d kernels for one polynomial order (-DBDG_ORDER=N).
 #include "sw2d_launch.hpp"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #ifndef BDG_ORDER
 #error "compile with -DBDG_ORDER=<polynomial order>"
@@ -240,10 +243,37 @@ hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
     const unsigned cap = p.gridCap > 0 ? static_cast<unsigned>(p.gridCap) : 256u;
     const unsigned grid = std::min((ntiles + 3u) / 4u, cap); // one four-wave workgroup per CU, one wave per SIMD
     static const int interleave = [] { const char* e = std::getenv("BDG_SW2D_TILE_INTERLEAVE"); return e ? std::atoi(e) : 1; }();
+    static const int stagger = [] { const char* e = std::getenv("BDG_SW2D_STAGGER"); return e ? std::atoi(e) : 0; }();
     StageParams pi = p;
     pi.tileInterleave = interleave;
+    pi.stagger = stagger;
+#ifdef BDG_PHASE_CLOCK
+    // profiling build: the per-wave phase cycles of the last launch go to $BDG_PHASE_CLOCK_FILE when the process exits
+    // (the buffer is pinned host memory the kernel writes directly, so nothing of HIP is needed at that point)
+    static unsigned long long* clockBuf = nullptr;
+    if (!clockBuf) {
+        if (hipHostMalloc(&clockBuf, 1024 * 16 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return hipErrorOutOfMemory;
+        std::memset(clockBuf, 0, 1024 * 16 * sizeof(unsigned long long));
+        static unsigned long long* dump = clockBuf;
+        std::atexit([] {
+            const char* name = std::getenv("BDG_PHASE_CLOCK_FILE");
+            if (FILE* f = name ? std::fopen(name, "w") : nullptr) {
+                for (unsigned w = 0; w < 1024; ++w) {
+                    std::fprintf(f, "%u", w);
+                    for (int i = 0; i < 16; ++i) std::fprintf(f, " %llu", dump[w * 16 + i]);
+                    std::fprintf(f, "\n");
+                }
+                std::fclose(f);
+            }
+        });
+    }
+    pi.phaseClock = clockBuf;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
     return hipGetLastError();
+#else
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
+    return hipGetLastError();
+#endif
 }
 
 // per-node geometry (StageParams::geo / fgeo) on the same schedule

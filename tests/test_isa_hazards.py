@@ -51,3 +51,11 @@ def test_no_matrix_instruction_overwrites_an_operand_it_is_still_reading(tmp_pat
     # which their parity tests (reference fixtures at N = 8 included) show to be harmless
     new = [f for f in found if "mfma3" in f[0] or "curved" in f[0] or "strip" in f[0]]
     assert not new, new[:5]
+    if source == "sw2d_order.hip":
+        # A spilled register comes back through a scratch load followed by s_waitcnt vmcnt(0), which drains every
+        # prefetch the wave has in flight: the straight-sided, single-domain forms of the state-once kernel (what the
+        # benchmark and every affine mesh run) must not spill at the highest order.
+        spills = dict(re.findall(r"\.name:\s+(_ZN7bdg_dev23sw2d_stage_mfma3_kernel\w+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)",
+                                 asm.read_text()))
+        plain = {k: int(v) for k, v in spills.items() if "ELb0ELb0ELb0E" in k}
+        assert len(plain) == 3 and not any(plain.values()), plain
