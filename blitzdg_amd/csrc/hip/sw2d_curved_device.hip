@@ -77,7 +77,10 @@ struct bdg_sw2d_curved {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t bytes = 0;
-    Buf<double> qA, qB, res, rhs, gq, cubG, gaussG, rJ, zx, zy, fcor, cd, mmSide, cholSide, ops, filt;
+    Buf<double> qA, qB, res, rhs, gq, cubG, gaussG, coef, mmSide, cholSide, ops, filt;
+    // nodal coefficient planes inside coef (one allocation: the stage kernel reaches all of them through one buffer
+    // descriptor): 1 / J first, then whichever of zx, zy, f, CD the caller gave (nullptr: absent)
+    double *rJ = nullptr, *zx = nullptr, *zy = nullptr, *fcor = nullptr, *cd = nullptr;
     Buf<int> gmapP, gmapM, curvedSlot, curvedEls, affineEl;
     Buf<double> cubAffine, cubWref;
     int numAffine = 0;
@@ -110,7 +113,7 @@ struct bdg_sw2d_curved {
     bdg_dev::CurvedParams params() const {
         bdg_dev::CurvedParams p{};
         p.gq = gq.p; p.cubG = cubG.p; p.gaussG = gaussG.p; p.gmapP = gmapP.p; p.gmapM = identityM ? nullptr : gmapM.p;
-        p.rJ = rJ.p; p.zx = zx.p; p.zy = zy.p; p.fcor = fcor.p; p.cd = cd.p; p.fconst = fconst; p.cdconst = cdconst;
+        p.rJ = rJ; p.zx = zx; p.zy = zy; p.fcor = fcor; p.cd = cd; p.fconst = fconst; p.cdconst = cdconst;
         p.curvedSlot = numCurved ? curvedSlot.p : nullptr;
         p.mmSide = mmSide.p; p.cholSide = cholSide.p; p.curvedEls = curvedEls.p; p.numCurved = numCurved; p.sideLd = sideLd;
         p.affineEl = numAffine ? affineEl.p : nullptr; p.cubAffine = numAffine ? cubAffine.p : nullptr; p.cubWref = cubWref.p;
@@ -178,8 +181,10 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
     const int CR = 16 * ncb, GR = 48 * fb, KV = kt->KV, MT = kt->MT;
     const long long ld = s->ld;
     // lane addresses are a row pointer plus an unsigned 32-bit BYTE offset within one plane
-    if (static_cast<long long>(std::max({Np, CR, GR})) * ld * 8 > 4294967295LL)
-        throw arg_error("bdg_sw2d_curved_create: a table plane exceeds 4 GiB (32-bit byte offsets): partition the mesh");
+    // (the state, trace and coefficient arrays are reached through ONE descriptor each, the plane picked by a 32-bit scalar
+    // offset: 4 state / trace planes, up to 5 coefficient planes; the cubature planes have a descriptor each)
+    if (static_cast<long long>(std::max({5 * Np, CR, 4 * GR})) * ld * 8 > 4294967295LL)
+        throw arg_error("bdg_sw2d_curved_create: a table exceeds 4 GiB (32-bit byte offsets): partition the mesh");
 
     // ---- index tables, validated on the host before anything touches the GPU
     const long long nG = static_cast<long long>(NG3) * K;
@@ -314,24 +319,26 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         s->uploadRows(offM.data(), s->gmapM.p, GR);
     }
     // ---- nodal tables
-    s->rJ.alloc(s->plane(), s->bytes, st);
     {
+        const double* given[4] = {d.zx, d.zy, d.coriolis, d.drag};
+        int planes = 1;
+        for (const double* g4 : given) planes += g4 ? 1 : 0;
+        s->coef.alloc(static_cast<size_t>(planes) * s->plane(), s->bytes, st);
+        s->rJ = s->coef.p;
         std::vector<double> tmp(static_cast<size_t>(Np) * K);
         for (size_t i = 0; i < tmp.size(); ++i) {
             if (!(d.J[i] > 0.0)) throw arg_error("bdg_sw2d_curved_create: nodal Jacobian J must be positive");
             tmp[i] = 1.0 / d.J[i];
         }
-        s->uploadRows(tmp.data(), s->rJ.p, Np);
+        s->uploadRows(tmp.data(), s->rJ, Np);
+        double** slot[4] = {&s->zx, &s->zy, &s->fcor, &s->cd};
+        int next = 1;
+        for (int i = 0; i < 4; ++i) {
+            if (!given[i]) continue;
+            *slot[i] = s->coef.p + static_cast<size_t>(next++) * s->plane();
+            s->uploadRows(given[i], *slot[i], Np);
+        }
     }
-    auto nodal = [&](const double* host, Buf<double>& buf) {
-        if (!host) return;
-        buf.alloc(s->plane(), s->bytes, st);
-        s->uploadRows(host, buf.p, Np);
-    };
-    nodal(d.zx, s->zx);
-    nodal(d.zy, s->zy);
-    nodal(d.coriolis, s->fcor);
-    nodal(d.drag, s->cd);
     s->fconst = d.coriolis_const;
     s->cdconst = d.drag_const;
 

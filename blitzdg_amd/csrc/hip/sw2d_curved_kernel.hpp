@@ -223,10 +223,10 @@ __device__ __forceinline__ void curved_sources(const CurvedParams& p, double h, 
     S3 = -(f * hu - cdn * v) - p.g * h * zy;
 }
 
-// Buffer addressing (as in sw2d_mfma3_kernel.hpp): one wave-uniform descriptor per plane, ONE per-lane byte offset per tile
-// ((q ld + k) 8: lane (q, j) touches rows 4 t + q / 16 b + 4 reg + q of its element k) and the row group as scalar offset, so
-// no 64-bit address per load sits in vector registers. The hardware range check covers the vector offset only: lanes on
-// padding rows get an out-of-range one (loads return 0, stores are dropped).
+// Buffer addressing (as in sw2d_mfma3_kernel.hpp): wave-uniform descriptors, ONE per-lane byte offset per tile
+// ((q ld + k) 8: lane (q, j) touches rows 4 t + q / 16 b + 4 reg + q of its element k) and the plane and row group as scalar
+// offset, so no 64-bit address per load sits in vector registers. An access is dropped (loads return 0) when vector +
+// scalar offset reaches the descriptor's size: lanes on padding rows get a vector offset of 0xfffffff8 for that.
 typedef unsigned int cbdg_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cplane_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
@@ -276,24 +276,25 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
     const unsigned ld8 = static_cast<unsigned>(ld) * 8u, ld4 = static_cast<unsigned>(ld) * 4u;
     const unsigned planeB = static_cast<unsigned>(plane * 8), gplaneB = static_cast<unsigned>(gplane * 8),
                    cplaneB = static_cast<unsigned>(cplane * 8);
-    __amdgpu_buffer_rsrc_t rq[4], rold[4], rout[4], rres[4], rgq[4], rcub[4], rgg[3];
+    // One descriptor per ARRAY (all its planes; the plane -- field c, table i -- is picked by the scalar offset). 35 per-plane
+    // descriptors (140 scalar registers) were spilled to vector-register lanes and read back, four v_readlane per use. The
+    // range check compares vector + scalar offset with the array's size (profiles/microbench/buffer_range_check.hip), so
+    // an array stays below 4 GiB (checked at creation) and the padding rows of a plane are taken out by nodeOff below.
+    // The cubature geometry keeps a descriptor per plane: its planes are the big ones.
+    const unsigned ncoef = 1u + (p.zx ? 1u : 0u) + (p.zy ? 1u : 0u) + (p.fcor ? 1u : 0u) + (p.cd ? 1u : 0u);
+    const __amdgpu_buffer_rsrc_t rq = cplane_rsrc(p.qin, 4u * planeB),
+                                 rold = cplane_rsrc(MODE == CMODE_LSERK ? p.res : (MODE == CMODE_COMBINE ? p.qbase : p.qin), 4u * planeB),
+                                 rout = cplane_rsrc(MODE == CMODE_RHS ? p.rhs : p.qout, 4u * planeB),
+                                 rgq = cplane_rsrc(p.gq, 4u * gplaneB), rgg = cplane_rsrc(p.gaussG, 3u * gplaneB);
+    __amdgpu_buffer_rsrc_t rcub[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        rq[c] = cplane_rsrc(p.qin + c * plane, planeB);
-        rold[c] = cplane_rsrc((MODE == CMODE_LSERK ? p.res : (MODE == CMODE_COMBINE ? p.qbase : p.qin)) + c * plane, planeB);
-        rout[c] = cplane_rsrc((MODE == CMODE_RHS ? p.rhs : p.qout) + c * plane, planeB);
-        rres[c] = cplane_rsrc((MODE == CMODE_LSERK ? p.res : p.qin) + c * plane, planeB);
-        rgq[c] = cplane_rsrc(p.gq + c * gplane, gplaneB);
-        rcub[c] = cplane_rsrc(p.cubG + c * cplane, cplaneB);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) rgg[i] = cplane_rsrc(p.gaussG + i * gplane, gplaneB);
+    for (int c = 0; c < 4; ++c) rcub[c] = cplane_rsrc(p.cubG + c * cplane, cplaneB);
     const __amdgpu_buffer_rsrc_t rmapP = cplane_rsrc(p.gmapP, static_cast<unsigned>(gplane * 4)),
                                  rmapM = cplane_rsrc(p.gmapM ? p.gmapM : p.gmapP, static_cast<unsigned>(gplane * 4)),
-                                 rrJ = cplane_rsrc(p.rJ, planeB), rzx = cplane_rsrc(p.zx ? p.zx : p.rJ, planeB),
-                                 rzy = cplane_rsrc(p.zy ? p.zy : p.rJ, planeB), rfc = cplane_rsrc(p.fcor ? p.fcor : p.rJ, planeB),
-                                 rcd = cplane_rsrc(p.cd ? p.cd : p.rJ, planeB),
+                                 rcoef = cplane_rsrc(p.rJ, ncoef * planeB), // rJ [, zx, zy, fcor, cd]: planes of ONE allocation
                                  raff = cplane_rsrc(p.cubAffine ? p.cubAffine : p.rJ, 4u * ld8);
+    const unsigned soZx = p.zx ? static_cast<unsigned>((p.zx - p.rJ) * 8) : 0u, soZy = p.zy ? static_cast<unsigned>((p.zy - p.rJ) * 8) : 0u,
+                   soFc = p.fcor ? static_cast<unsigned>((p.fcor - p.rJ) * 8) : 0u, soCd = p.cd ? static_cast<unsigned>((p.cd - p.rJ) * 8) : 0u;
     const double g = p.g;
     const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u;
     unsigned tile, tileEnd;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int t = 0; t < KV; ++t) qB[c][t] = cbld_f64(rq[c], nodeOff(t), static_cast<unsigned>(4 * t) * ld8);
+            for (int t = 0; t < KV; ++t) qB[c][t] = cbld_f64(rq, nodeOff(t), static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8);
         // straight-sided tile? (one ballot; padding lanes repeat the last element)
         bool affTile = false;
         double ca[4] = {0.0, 0.0, 0.0, 0.0};
@@ -421,15 +422,15 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
                     double hM, huM, hvM, hNM;
                     if constexpr (MAPM) {
                         const unsigned oM = static_cast<unsigned>(cbld_i32(rmapM, v4, so4)) * 8u;
-                        hM = cbld_f64(rgq[0], oM, 0u); huM = cbld_f64(rgq[1], oM, 0u);
-                        hvM = cbld_f64(rgq[2], oM, 0u); hNM = cbld_f64(rgq[3], oM, 0u);
+                        hM = cbld_f64(rgq, oM, 0u); huM = cbld_f64(rgq, oM, gplaneB);
+                        hvM = cbld_f64(rgq, oM, 2u * gplaneB); hNM = cbld_f64(rgq, oM, 3u * gplaneB);
                     } else {
                         hM = gM[0][reg]; huM = gM[1][reg]; hvM = gM[2][reg]; hNM = gM[3][reg];
                     }
-                    double hP = cbld_f64(rgq[0], oP, 0u), huP = cbld_f64(rgq[1], oP, 0u), hvP = cbld_f64(rgq[2], oP, 0u),
-                           hNP = cbld_f64(rgq[3], oP, 0u);
-                    const double nx = cbld_f64(rgg[0], v8, so8), ny = cbld_f64(rgg[1], v8, so8),
-                                 hW = 0.5 * cbld_f64(rgg[2], v8, so8); // zero on padding rows
+                    double hP = cbld_f64(rgq, oP, 0u), huP = cbld_f64(rgq, oP, gplaneB), hvP = cbld_f64(rgq, oP, 2u * gplaneB),
+                           hNP = cbld_f64(rgq, oP, 3u * gplaneB);
+                    const double nx = cbld_f64(rgg, v8, so8), ny = cbld_f64(rgg, v8, gplaneB + so8),
+                                 hW = 0.5 * cbld_f64(rgg, v8, 2u * gplaneB + so8); // zero on padding rows
                     if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
                     const double rM = crcp(hM), rP = crcp(hP);
                     // the wave speeds use the exterior velocity BEFORE the wall condition (rhs.py:81-85, :93-94)
@@ -484,14 +485,14 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
         for (int t = 0; t < KV; ++t) {
             const int m = 4 * t + static_cast<int>(q);
             const unsigned so = static_cast<unsigned>(4 * t) * ld8, vo = nodeOff(t);
-            const double rj = cbld_f64(rrJ, vo, so); // 0 on padding rows
+            const double rj = cbld_f64(rcoef, vo, so); // 0 on padding rows
             {   // momentum sources at the node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx, S3 = -(f hu - CD |u| v) - g h zy
                 const double h = m < Np ? qB[0][t] : 1.0, hu = qB[1][t], hv = qB[2][t];
                 const double rh = crcp(h);
                 const double u = hu * rh, v = hv * rh;
-                const double fco = p.fcor ? cbld_f64(rfc, vo, so) : p.fconst, cdv = p.cd ? cbld_f64(rcd, vo, so) : p.cdconst;
+                const double fco = p.fcor ? cbld_f64(rcoef, vo, soFc + so) : p.fconst, cdv = p.cd ? cbld_f64(rcoef, vo, soCd + so) : p.cdconst;
                 const double cdn = cdv * csqrt(u * u + v * v);
-                const double zx = p.zx ? cbld_f64(rzx, vo, so) : 0.0, zy = p.zy ? cbld_f64(rzy, vo, so) : 0.0;
+                const double zx = p.zx ? cbld_f64(rcoef, vo, soZx + so) : 0.0, zy = p.zy ? cbld_f64(rcoef, vo, soZy + so) : 0.0;
                 S2[t] = m < Np ? (fco * hv - cdn * u) - g * h * zx : 0.0;
                 S3[t] = m < Np ? -(fco * hu - cdn * v) - g * h * zy : 0.0;
             }
@@ -521,15 +522,15 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
                     }
                     double R = out[c][t >> 2][t & 3];
                     if constexpr (!FILTER) R += c == 1 ? S2[t] : (c == 2 ? S3[t] : 0.0);
-                    const unsigned so = static_cast<unsigned>(4 * t) * ld8;
+                    const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
                     if constexpr (MODE == CMODE_RHS) {
-                        cbst_f64(rout[c], v8, so, R);
+                        cbst_f64(rout, v8, so, R);
                     } else if constexpr (MODE == CMODE_LSERK) {
-                        const double n1 = p.ca * cbld_f64(rold[c], v8, so) + p.cc * R;
-                        cbst_f64(rres[c], v8, so, n1);
-                        cbst_f64(rout[c], v8, so, qB[c][t] + p.cb * n1);
+                        const double n1 = p.ca * cbld_f64(rold, v8, so) + p.cc * R;
+                        cbst_f64(rold, v8, so, n1); // the residual, in place
+                        cbst_f64(rout, v8, so, qB[c][t] + p.cb * n1);
                     } else {
-                        cbst_f64(rout[c], v8, so, p.ca * cbld_f64(rold[c], v8, so) + p.cb * qB[c][t] + p.cc * R);
+                        cbst_f64(rout, v8, so, p.ca * cbld_f64(rold, v8, so) + p.cb * qB[c][t] + p.cc * R);
                     }
                 }
         }

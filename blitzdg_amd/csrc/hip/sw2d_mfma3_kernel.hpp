@@ -32,10 +32,11 @@ namespace bdg_dev {
 
 // Row accesses go through buffer instructions: a wave-uniform descriptor per plane, ONE per-lane byte offset per tile
 // ((q ld + k) 8: lane (q, j) always touches rows 4 t + q of its element k) and the row group 4 t as a scalar offset.
-// No per-load 64-bit address lives in vector registers (72 row loads in flight would need 144 of them). The hardware's
-// range check of a raw buffer looks at the VECTOR offset only (the scalar offset is added after it), so the padding
-// nodes m >= Np of the last k-step are taken out by giving those lanes an out-of-range vector offset (row_voffset):
-// their loads return 0 and their stores are dropped, and nothing beyond a plane is ever touched.
+// No per-load 64-bit address lives in vector registers (72 row loads in flight would need 144 of them). The hardware
+// drops an access whose vector + scalar offset reaches the descriptor's size (profiles/microbench/buffer_range_check.hip;
+// no 32-bit wrap-around in the sum), which already takes out the padding nodes m >= Np of the last k-step of a plane that
+// has its own descriptor; those lanes also get an out-of-range vector offset (row_voffset), so the same holds where one
+// descriptor spans several planes: their loads return 0, their stores are dropped, nothing beyond a plane is touched.
 typedef unsigned int bdg_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t plane_rsrc(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
