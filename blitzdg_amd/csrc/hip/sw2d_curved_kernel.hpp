@@ -260,11 +260,15 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
     constexpr int fb = FB;
     const int offDrT = O::offDrT(ncb, fb), offDsT = O::offDsT(ncb, fb), offIT = O::offIT(ncb, fb),
               offMass = FILTER ? O::offMF(ncb, fb) : O::offM(ncb, fb), offF = O::offF(ncb, fb), offGI = O::offGI(ncb, fb);
+    // reference weights of the straight elements behind the image (a global read per cubature row would be a round trip
+    // to L1 each, sixteen of them per tile in a row)
+    const int wrefAt = OPSLDS ? O::tiles(ncb, fb) * 64 : 0;
     if constexpr (OPSLDS) {
         const int n = O::tiles(ncb, fb) * 64;
         for (int t = threadIdx.x; t < n; t += blockDim.x) sOps[t] = p.ops[t];
-        __syncthreads();
     }
+    for (int t = threadIdx.x; t < 16 * ncb; t += blockDim.x) sOps[wrefAt + t] = p.cubWref ? p.cubWref[t] : 0.0;
+    __syncthreads();
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
     auto A = [&](int tile) -> double {
         if constexpr (OPSLDS) return sOps[tile * 64 + static_cast<int>(lane)];
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
                 const unsigned so = static_cast<unsigned>(16 * rb + 4 * reg) * ld8;
                 double wrx, wry, wsx, wsy;
                 if (affTile) { // rule weight (times a reference Jacobian) of this point, the element's four numbers
-                    const double w = p.cubWref[row]; // zero on padding rows
+                    const double w = sOps[wrefAt + row]; // zero on padding rows
                     wrx = w * ca[0]; wry = w * ca[1]; wsx = w * ca[2]; wsy = w * ca[3];
                 } else {
                     wrx = cbld_f64(rcub[0], v8, so); wry = cbld_f64(rcub[1], v8, so);

@@ -66,7 +66,8 @@ hipError_t launchStage(const CurvedParams& p, hipStream_t stream) {
 template <int MODE, bool FILTER, int FB, int WAVES, bool MAPM>
 hipError_t launchStageFb(const CurvedParams& p, hipStream_t stream) {
     if (p.K < 1) return hipSuccess;
-    const size_t lds = static_cast<size_t>(O::tiles(p.ncb, p.fb)) * 64 * sizeof(double);
+    const size_t wref = static_cast<size_t>(16 * p.ncb) * sizeof(double); // reference weights of straight elements, behind the image
+    const size_t lds = static_cast<size_t>(O::tiles(p.ncb, p.fb)) * 64 * sizeof(double) + wref;
     if (lds <= static_cast<size_t>(kLdsBudgetBytes)) {
         auto kern = sw2d_curved_stage_kernel<kN, MODE, FILTER, true, FB, WAVES, MAPM>;
         if (lds > 64 * 1024) {
@@ -77,7 +78,7 @@ hipError_t launchStageFb(const CurvedParams& p, hipStream_t stream) {
         const int wgPerCu = std::max(1, static_cast<int>(160 * 1024 / std::max<size_t>(lds, 1)));
         hipLaunchKernelGGL(kern, dim3(gridFor(p.K, std::min(wgPerCu, 2))), dim3(256), lds, stream, p);
     } else {
-        hipLaunchKernelGGL((sw2d_curved_stage_kernel<kN, MODE, FILTER, false, FB, WAVES, MAPM>), dim3(gridFor(p.K, 2)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((sw2d_curved_stage_kernel<kN, MODE, FILTER, false, FB, WAVES, MAPM>), dim3(gridFor(p.K, 2)), dim3(256), wref, stream, p);
     }
     return hipGetLastError();
 }
