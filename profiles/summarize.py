@@ -17,10 +17,17 @@ import sys
 from collections import defaultdict
 
 
+def newest(pattern):
+    """gpurun merges a call's files into gpurun_out/ without removing those of earlier calls: only the newest CSV of a
+    directory belongs to the collection being summarized."""
+    files = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return files[-1:]
+
+
 def counters(path, kernel_substr):
     agg = defaultdict(list)
     extra = {}
-    for f in glob.glob(os.path.join(path, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(path, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -53,7 +60,7 @@ def main():
             summary["resources"] = extra
     # calibration of the FETCH_SIZE factor on a kernel whose bytes are known: the (15, K) upload
     cal, _, cx = counters(os.path.join(out, f"prof_{tag}_fetch"), "scatter_rows_kernel<double>")
-    stats = glob.glob(os.path.join(out, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
+    stats = newest(os.path.join(out, f"prof_{tag}_trace", "*", "*_kernel_stats.csv"))
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         for r in rows:
@@ -65,7 +72,7 @@ def main():
                 break
     # the timed region of bench.py = the LAST 200 stage launches of the traced run (before them: the untimed
     # clock-ramp blocks and the warm-up, during which a fresh box is still raising its clocks)
-    traces = glob.glob(os.path.join(out, f"prof_{tag}_trace", "*", "*_kernel_trace.csv"))
+    traces = newest(os.path.join(out, f"prof_{tag}_trace", "*", "*_kernel_trace.csv"))
     if traces:
         durs = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 for r in csv.DictReader(open(traces[0])) if stage in r["Kernel_Name"]]
