@@ -428,6 +428,9 @@ typedef struct bdg_sw2d_curved_desc {
     int device;
     int flags;            /* 0                                                                */
 } bdg_sw2d_curved_desc;
+/* Size limit of one solver: device tables are addressed with 32-bit byte offsets, so max(5 Np, 16 ceil(num_cub / 16),
+ * 192 ceil(num_gauss / 16)) * ld * 8 must stay below 4 GiB (ld = num_elements rounded up to 64): 2.8 million elements at
+ * N = 4 with the builders' default rules, 2.5 million at N = 8. BDG_ERR_ARGUMENT beyond it: partition the mesh. */
 int bdg_sw2d_curved_create(const bdg_sw2d_curved_desc* desc, bdg_sw2d_curved** out);
 void bdg_sw2d_curved_destroy(bdg_sw2d_curved* s);
 /* The reference function itself: host (Np, K) fields in, host RHS out; filter != 0 returns Filter * RHS
