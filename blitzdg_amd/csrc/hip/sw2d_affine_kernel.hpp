@@ -94,7 +94,9 @@ struct PhysParams {
 };
 
 // TRACER: the passive tracer hN (field 3; F4 = hN u, G4 = hN v, no sources) in the same pass.
-template <int N, int MODE, int PHYS = 0, bool TRACER = false>
+// SPONGE (MODE_COMBINE only): the momentum relaxation of the SSP-RK2 + sponge scheme is applied after the update; a
+// launch with StageParams::sponge == 0 takes the instance without it.
+template <int N, int MODE, int PHYS = 0, bool TRACER = false, bool SPONGE = false>
 __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParams p, const PhysParams ph) {
     using E = Elem<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN;
@@ -135,11 +137,21 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     // source planes ride in the same batch and are consumed right away (they seed R2, R3 below)
     double ssx[PHYS != 0 ? Np : 1], ssy[PHYS != 0 ? Np : 1], sfc[PHYS != 0 ? Np : 1];
     if constexpr (PHYS != 0) {
+        // (a table that is absent is a constant: decided once per TABLE, not per node -- 3 Np little branches in the
+        // unrolled body cost the scheduler its one big region, see the update at the end)
 #pragma unroll
-        for (int i = 0; i < Np; ++i) {
-            ssx[i] = ph.sx ? ld_row(ph.sx + i * ld, k8) : 0.0;
-            ssy[i] = ph.sy ? ld_row(ph.sy + i * ld, k8) : 0.0;
-            sfc[i] = ph.fcor ? ld_row(ph.fcor + i * ld, k8) : ph.fconst;
+        for (int i = 0; i < Np; ++i) { ssx[i] = 0.0; ssy[i] = 0.0; sfc[i] = ph.fconst; }
+        if (ph.sx) {
+#pragma unroll
+            for (int i = 0; i < Np; ++i) ssx[i] = ld_row(ph.sx + i * ld, k8);
+        }
+        if (ph.sy) {
+#pragma unroll
+            for (int i = 0; i < Np; ++i) ssy[i] = ld_row(ph.sy + i * ld, k8);
+        }
+        if (ph.fcor) {
+#pragma unroll
+            for (int i = 0; i < Np; ++i) sfc[i] = ld_row(ph.fcor + i * ld, k8);
         }
     }
     // Keep the loads above in one batch: without this the scheduler sinks each load next to
@@ -343,13 +355,21 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             }
         }
     } else {
+        // The sponge (a division per momentum value) is a template parameter: with the test inside sponge_relax the unrolled
+        // body became 2 Np little branches, the scheduler lost its one big region, the operator entries (scalar loads) were
+        // all hoisted and spilled -- 1369 scalar and 283-666 vector registers, 1.56 ms per evaluation at N = 4 where the
+        // LSERK form of the same kernel takes 0.35; and even one branch around two copies of the loop cost the tracer +
+        // sources form 118 spilled vector registers.
+        static_assert(!SPONGE || MODE == MODE_COMBINE, "the sponge follows a combine step");
         double* __restrict__ o = p.qout;
         const double a = p.ca, b = p.cb, c = p.cc;
+        const double sg = p.sponge;
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
+            const double v2 = a * old2[i] + b * hu[i] + c * R2[i], v3 = a * old3[i] + b * hv[i] + c * R3[i];
             st_row(o + i * ld, k8, a * old1[i] + b * h[i] + c * R1[i]);
-            st_row(o + plane + i * ld, k8, sponge_relax(a * old2[i] + b * hu[i] + c * R2[i], p.sponge));
-            st_row(o + 2 * plane + i * ld, k8, sponge_relax(a * old3[i] + b * hv[i] + c * R3[i], p.sponge));
+            st_row(o + plane + i * ld, k8, SPONGE ? v2 / (1.0 + sg * v2 * v2) : v2);
+            st_row(o + 2 * plane + i * ld, k8, SPONGE ? v3 / (1.0 + sg * v3 * v3) : v3);
             if constexpr (TRACER) st_row(o + 3 * plane + i * ld, k8, a * old4[i] + b * hN[i] + c * R4[i]);
         }
     }

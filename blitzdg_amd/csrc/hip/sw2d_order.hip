@@ -80,6 +80,12 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
     else {
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kUnrolledBlock - 1) / kUnrolledBlock);
+    if constexpr (MODE == MODE_COMBINE) {
+        if (p.sponge != 0.0) {
+            hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 0, false, true>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
     return hipGetLastError();
     }
@@ -93,6 +99,18 @@ hipError_t launchAffineSrc(const StageParams& p, const PhysParams& ph, int trace
     if (p.kend <= p.kbegin) return hipSuccess;
     const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kUnrolledBlock - 1) / kUnrolledBlock);
     const dim3 blk(kUnrolledBlock);
+    if constexpr (MODE == MODE_COMBINE) {
+        if (p.sponge != 0.0) { // the instances with the momentum relaxation
+            if (tracer) {
+                if (ph.fmat) hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 2, true, true>), dim3(grid), blk, 0, stream, p, ph);
+                else hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 1, true, true>), dim3(grid), blk, 0, stream, p, ph);
+            } else {
+                if (ph.fmat) hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 2, false, true>), dim3(grid), blk, 0, stream, p, ph);
+                else hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 1, false, true>), dim3(grid), blk, 0, stream, p, ph);
+            }
+            return hipGetLastError();
+        }
+    }
     if (tracer) {
         if (ph.fmat) hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 2, true>), dim3(grid), blk, 0, stream, p, ph);
         else hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE, 1, true>), dim3(grid), blk, 0, stream, p, ph);

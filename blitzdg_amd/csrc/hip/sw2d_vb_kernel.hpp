@@ -475,13 +475,25 @@ __global__ __launch_bounds__(256) void sw2d_stage_vb_unrolled_kernel(const Stage
             st_row(p.qout + 2 * plane + i * ld, k8, hv[i]);
         }
     } else {
+        // Sponge coefficients: the nodal field if there is one, else the scalar, picked by a select and not by a branch
+        // (the load is issued either way), and the relaxation written without a test (x / (1 + 0 x^2) is x): a branch per
+        // node in this unrolled body -- even ONE branch around the loads -- cost the scheduler its one big region, every
+        // operator entry was hoisted and spilled (1314-1770 scalar, 432-474 vector registers).
         const double a = p.ca, b = p.cb, c = p.cc;
+        double spv[Np];
+        const bool field = vp.sponge != nullptr;
+        const double* __restrict__ spp = field ? vp.sponge : p.qin; // (no field: any valid plane, the value is not used)
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
-            const double sp = vp.sponge ? ld_row(vp.sponge + i * ld, k8) : p.sponge;
+            const double v = ld_row(spp + i * ld, k8);
+            spv[i] = field ? v : p.sponge;
+        }
+#pragma unroll
+        for (int i = 0; i < Np; ++i) {
+            const double v2 = a * old2[i] + b * hu[i] + c * R2[i], v3 = a * old3[i] + b * hv[i] + c * R3[i];
             h[i] = a * old1[i] + b * h[i] + c * R1[i];
-            hu[i] = sponge_relax(a * old2[i] + b * hu[i] + c * R2[i], sp);
-            hv[i] = sponge_relax(a * old3[i] + b * hv[i] + c * R3[i], sp);
+            hu[i] = v2 / (1.0 + spv[i] * v2 * v2);
+            hv[i] = v3 / (1.0 + spv[i] * v3 * v3);
             st_row(p.qout + i * ld, k8, h[i]);
             st_row(p.qout + plane + i * ld, k8, hu[i]);
             st_row(p.qout + 2 * plane + i * ld, k8, hv[i]);

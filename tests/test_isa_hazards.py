@@ -59,3 +59,23 @@ def test_no_matrix_instruction_overwrites_an_operand_it_is_still_reading(tmp_pat
                                  asm.read_text()))
         plain = {k: int(v) for k, v in spills.items() if "ELb0ELb0ELb0E" in k}
         assert len(plain) == 3 and not any(plain.values()), plain
+
+
+def test_unrolled_kernels_keep_their_one_scheduling_region(tmp_path):
+    """The one-lane-per-element kernels of N <= 4 are one huge unrolled basic block whose operator entries are scalar
+    loads the scheduler streams in as it goes. A run-time branch per node inside that body (a sponge test per momentum
+    value, `table ? load : constant` per node) splits the region: every operator entry is hoisted and spilled -- the
+    midpoint-RK2 / SSP-RK2 forms at N = 4 spilled 1300-1800 scalar and 280-670 vector registers and ran 4-9 times slower
+    than the LSERK form of the same kernel until those tests were moved out of the body. Guard: no instance of these
+    kernels spills more than a few dozen vector registers, in any time-stepping mode."""
+    asm = tmp_path / "k4.s"
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-DBDG_ORDER=4",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "blitzdg_amd", "csrc", "host"), "-I" + HIP,
+           "--cuda-device-only", "-S", os.path.join(HIP, "sw2d_order.hip"), "-o", str(asm)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    spills = re.findall(r"\.name:\s+(_ZN7bdg_dev\d+(?:sw2d_stage_affine_kernel|sw2d_stage_vb_unrolled_kernel)\w+)\n(?:.*\n)*?"
+                        r"\s+\.vgpr_spill_count:\s+(\d+)", asm.read_text())
+    assert len(spills) >= 20, len(spills)                       # every mode x physics x tracer instance was seen
+    worst = max(spills, key=lambda kv: int(kv[1]))
+    assert int(worst[1]) <= 64, worst
