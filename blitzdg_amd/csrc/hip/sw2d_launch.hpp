@@ -8,6 +8,7 @@
 #include "sw2d_vb_kernel.hpp"
 #include "sw2d_mfma_kernel.hpp"
 #include "sw2d_mfma3_kernel.hpp"
+#include "sw2d_mfma3src_kernel.hpp"
 #include "sw2d_kernels.hpp"
 
 namespace bdg_dev {
@@ -33,9 +34,12 @@ struct KernelTable {
     hipError_t (*stageMfma3Halo)(const StageParams& p, hipStream_t stream); // MODE_LSERK with the halo staging folded in
     // per-node geometry (geo / fgeo planes); filter: plain operators + MT*KV Filter tiles in the image
     hipError_t (*stageMfma3Nodal)(int mode, bool filter, const StageParams& p, hipStream_t stream);
-    // N >= 6: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the
-    // tracer-equation pass (plain MfmaOps2 image); tracer = 2: variant B (image as for the sources)
+    // N >= 5: the same kernel with momentum sources (image = MfmaOps2 + MT*KV tiles of F'); tracer = 1: the
+    // tracer-equation pass (plain MfmaOps2 image); tracer = 2: variant B (image as for the sources); tracer = 3: sources +
+    // tracer in one pass (MT <= 2); tracer = 4 / 5: sources without / with the tracer on the state-once schedule
+    // (sw2d_mfma3src_kernel.hpp; hipErrorNotSupported where its LDS tiles or registers do not fit: see mfma3SrcFields)
     hipError_t (*stageMfma2Src)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);
+    int mfma3SrcFields; // 0: no state-once kernel with sources at this order; else the number of fields it takes (up to)
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);

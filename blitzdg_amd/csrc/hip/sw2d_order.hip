@@ -28,6 +28,10 @@ constexpr bool kNoUnrolledSources = BDG_ORDER > 4;
 constexpr bool kNoStream = BDG_ORDER > 5;
 // The matrix-core source-term / tracer / variant-B kernels exist from this order up.
 constexpr bool kMfmaSources = BDG_ORDER >= 5;
+// state-once kernel with sources (sw2d_mfma3src_kernel.hpp), with the tracer too, at N = 5, 6, 7 (N = 7 with tracer: 501-512
+// registers, 3 spilled in the combine form and still 1.9 times the two-wave kernels); N = 8 does not fit: operators + F'
+// tiles + four waves' state tiles exceed 160 KB of LDS, and three fields alone already take 488 registers
+constexpr int kMfma3SrcFields = (BDG_ORDER >= 5 && BDG_ORDER <= 7) ? 4 : 0;
 
 // Rolled kernels. FIELDS = 1 (three waves per 64 elements, one field each) exists for every
 // order; FIELDS = 3 (all fields per lane) only where 3*Np accumulators fit (N <= 6).
@@ -350,6 +354,30 @@ hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer
     const unsigned waves = tracer == 1 ? 3u : static_cast<unsigned>(BDG_MFMA2_WAVES);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(waves, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
+    if (tracer == 4 || tracer == 5) { // state-once schedule with sources (and tracer)
+        if constexpr (kMfma3SrcFields == 0) return hipErrorNotSupported;
+        else {
+            if (tracer == 5 && kMfma3SrcFields < 4) return hipErrorNotSupported;
+            const long long arrayBytes = static_cast<long long>(tracer == 5 ? 4 : 3) * Elem<kN>::Np * p.ld * 8;
+            if (arrayBytes > 4294967295LL) return hipErrorNotSupported; // one descriptor per array
+            const unsigned grid3 = std::min((ntiles + 3u) / 4u, 256u); // one four-wave workgroup per CU
+            auto launch = [&](auto kern, size_t lds) -> hipError_t {
+                if (lds > 64 * 1024) {
+                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                             static_cast<int>(lds));
+                    if (e != hipSuccess) return e;
+                }
+                hipLaunchKernelGGL(kern, dim3(grid3), dim3(256), lds, stream, p, ph);
+                return hipGetLastError();
+            };
+            if (tracer == 5) {
+                if constexpr (kMfma3SrcFields >= 4)
+                    return launch(sw2d_stage_mfma3src_kernel<kN, MODE, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
+                else return hipErrorNotSupported;
+            }
+            return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
+        }
+    }
     if (tracer == 3) { // sources + tracer in one pass (MT <= 2)
         if constexpr (MfmaOps2<kN>::MT <= 2)
             hipLaunchKernelGGL((sw2d_stage_mfma2_kernel<kN, MODE, 1, true>), dim3(grid), dim3(256), ldsBytes, stream, p, ph);
@@ -461,7 +489,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, &stageMfma2Halo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma3Nodal, &stageMfma2Src, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
+                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma3Nodal, &stageMfma2Src, kMfma3SrcFields, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

@@ -962,6 +962,50 @@ def test_tracer_output_field_and_vtu(coarse_mesh, tmp_path):
         sw2d.Sw2dSolver(nodes=nodes).outputTracer()
 
 
+@pytest.mark.parametrize("order,nx,ny,fields", [(5, 37, 29, 4), (6, 30, 41, 4), (6, 21, 19, 3), (7, 23, 17, 3), (7, 19, 26, 4)])
+def test_state_once_kernel_with_sources_and_tracer_on_many_tiles(order, nx, ny, fields, monkeypatch):
+    """Variants C / D on the state-once schedule (sw2d_mfma3src_kernel.hpp: N = 5, 6, 7, with and without the tracer; the
+    default there) with several tiles per wave, a ragged last tile, a shuffled element order, array-valued bed
+    slopes and Coriolis parameter, against the two-waves-per-SIMD kernels it replaces (BDG_SW2D_SOURCES_TWO_WAVE=1,
+    themselves pinned by the reference fixtures above): RHS, filtered RHS, 11 LSERK4 stages, midpoint RK2 + filter and
+    SSP-RK2 + sponge steps agree to round-off."""
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(nx, ny, shuffleSeed=977)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    t = tables_from_nodes(nodes)
+    x, y = t["x"], t["y"]
+    h, hu, hv = seeded_fields(x, y, seed=order)
+    hN = h * (0.3 + 0.2 * np.sin(2 * x + y))
+    src = {"zx": 0.02 * np.cos(x) + 0.01, "zy": 0.015 * np.sin(2 * y), "f": 0.07 + 0.01 * y, "CD": 2.5e-3}
+    out = {}
+    for two_wave in (True, False):
+        if two_wave:
+            monkeypatch.setenv("BDG_SW2D_SOURCES_TWO_WAVE", "1")
+        else:
+            monkeypatch.delenv("BDG_SW2D_SOURCES_TWO_WAVE")
+        s = sw2d.Sw2dSolver(tables=t, g=9.81, flags=sw2d.KEEP_ORDER, fields=fields, sources=src)
+        q = (h, hu, hv, hN)[:fields]
+        set_state, get_state = (s.setState4, s.getState4) if fields == 4 else (s.setState, s.getState)
+        rhs_fn = s.computeRHS4 if fields == 4 else s.computeRHS
+        res = [rhs_fn(*q), rhs_fn(*q, filter=True)]
+        set_state(*q)
+        dt, _ = s.computeDt(0.4)
+        s.lserk4Stages(dt, 11)
+        res.append(get_state())
+        set_state(*q)
+        s.stepRK2(dt, 3, filter=True)
+        res.append(get_state())
+        set_state(*q)
+        s.stepSSPRK2(dt, 2, False, 1e-3)
+        res.append(get_state())
+        out[two_wave] = res
+    for a, b in zip(out[True], out[False]):
+        for u, v in zip(a, b):
+            assert relmax(v, u) < 1e-13
+    assert relmax(out[False][2][1], hu) > 1e-6                    # the state moved
+
+
 @pytest.mark.parametrize("case", ["coarse_box_N4", "coarse_box_N6"])
 def test_tracer_in_its_own_pass_as_cross_check(case, monkeypatch):
     """By default the tracer equation rides in the three-field kernel as a fourth accumulator set (N <= 6);
