@@ -34,16 +34,34 @@ def _overlaps(asm):
     return out
 
 
+UNITS = [("sw2d_order.hip", 8), ("sw2d_curved_order.hip", 8), ("sw2d_curved_order.hip", 4), ("sw2d_order.hip", 4)]
+
+
+@pytest.fixture(scope="module")
+def assembly(tmp_path_factory):
+    """Every translation unit the tests below read, compiled to assembly side by side (the slowest takes two minutes):
+    (source, order) -> text."""
+    out = tmp_path_factory.mktemp("isa")
+    procs = {}
+    for source, order in UNITS:
+        asm = out / f"{source}.{order}.s"
+        cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", f"-DBDG_ORDER={order}",
+               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "blitzdg_amd", "csrc", "host"), "-I" + HIP,
+               "--cuda-device-only", "-S", os.path.join(HIP, source), "-o", str(asm)]
+        procs[(source, order)] = (subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True), asm)
+    texts = {}
+    for key, (proc, asm) in procs.items():
+        _, err = proc.communicate(timeout=1500)
+        assert proc.returncode == 0, err[-3000:]
+        texts[key] = asm.read_text()
+    return texts
+
+
 @pytest.mark.parametrize("source,order", [("sw2d_order.hip", 8), ("sw2d_curved_order.hip", 8), ("sw2d_curved_order.hip", 4)])
-def test_no_matrix_instruction_overwrites_an_operand_it_is_still_reading(tmp_path, source, order):
-    asm = tmp_path / "k.s"
-    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", f"-DBDG_ORDER={order}",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "blitzdg_amd", "csrc", "host"), "-I" + HIP,
-           "--cuda-device-only", "-S", os.path.join(HIP, source), "-o", str(asm)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    found = _overlaps(asm.read_text())
-    assert MFMA.search(asm.read_text())                                  # the scan does see matrix instructions
+def test_no_matrix_instruction_overwrites_an_operand_it_is_still_reading(assembly, source, order):
+    text = assembly[(source, order)]
+    found = _overlaps(text)
+    assert MFMA.search(text)                                             # the scan does see matrix instructions
     # destination overlapping the A operand: never
     assert not [f for f in found if f[2] == "A"], found[:5]
     # ... and no overlap of any kind in the kernels of this round (state-once schedule, strip kernel, curved RHS); the
@@ -56,26 +74,21 @@ def test_no_matrix_instruction_overwrites_an_operand_it_is_still_reading(tmp_pat
         # prefetch the wave has in flight: the straight-sided, single-domain forms of the state-once kernel (what the
         # benchmark and every affine mesh run) must not spill at the highest order.
         spills = dict(re.findall(r"\.name:\s+(_ZN7bdg_dev23sw2d_stage_mfma3_kernel\w+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)",
-                                 asm.read_text()))
+                                 text))
         plain = {k: int(v) for k, v in spills.items() if "ELb0ELb0ELb0E" in k}
         assert len(plain) == 3 and not any(plain.values()), plain
 
 
-def test_unrolled_kernels_keep_their_one_scheduling_region(tmp_path):
+def test_unrolled_kernels_keep_their_one_scheduling_region(assembly):
     """The one-lane-per-element kernels of N <= 4 are one huge unrolled basic block whose operator entries are scalar
     loads the scheduler streams in as it goes. A run-time branch per node inside that body (a sponge test per momentum
     value, `table ? load : constant` per node) splits the region: every operator entry is hoisted and spilled -- the
     midpoint-RK2 / SSP-RK2 forms at N = 4 spilled 1300-1800 scalar and 280-670 vector registers and ran 4-9 times slower
     than the LSERK form of the same kernel until those tests were moved out of the body. Guard: no instance of these
     kernels spills more than a few dozen vector registers, in any time-stepping mode."""
-    asm = tmp_path / "k4.s"
-    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "--offload-arch=gfx950", "-DBDG_ORDER=4",
-           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "blitzdg_amd", "csrc", "host"), "-I" + HIP,
-           "--cuda-device-only", "-S", os.path.join(HIP, "sw2d_order.hip"), "-o", str(asm)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
+    text = assembly[("sw2d_order.hip", 4)]
     spills = re.findall(r"\.name:\s+(_ZN7bdg_dev\d+(?:sw2d_stage_affine_kernel|sw2d_stage_vb_unrolled_kernel)\w+)\n(?:.*\n)*?"
-                        r"\s+\.vgpr_spill_count:\s+(\d+)", asm.read_text())
+                        r"\s+\.vgpr_spill_count:\s+(\d+)", text)
     assert len(spills) >= 20, len(spills)                       # every mode x physics x tracer instance was seen
     worst = max(spills, key=lambda kv: int(kv[1]))
     assert int(worst[1]) <= 64, worst
