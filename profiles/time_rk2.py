@@ -2,7 +2,8 @@
 evaluations per step, fused with the combine (MODE_COMBINE), against the LSERK4 stage of the same solver.
   python3 profiles/time_rk2.py <order> <NXxNY>"""
 import sys, time, json, numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import blitzdg_amd.pyblitzdg as dg
 from blitzdg_amd import sw2d
 order = int(sys.argv[1]) if len(sys.argv) > 1 else 4

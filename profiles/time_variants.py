@@ -1,5 +1,6 @@
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import blitzdg_amd.pyblitzdg as dg
 from blitzdg_amd import sw2d
 order = int(sys.argv[1]) if len(sys.argv) > 1 else 4
