@@ -96,6 +96,8 @@ _SIGNATURES = {
     "bdg_mesh_destroy": (None, [_P]),
     "bdg_mesh_read": (c_int, [_P, c_char_p]),
     "bdg_mesh_write": (c_int, [_P, c_char_p]),
+    "bdg_mesh_write_cache": (c_int, [_P, c_char_p]),
+    "bdg_mesh_read_cache": (c_int, [_P, c_char_p]),
     "bdg_mesh_build": (c_int, [_P, _P, c_int, _P, c_int, c_int]),
     "bdg_mesh_build_box": (c_int, [_P, c_int, c_int, c_double, c_double, c_double, c_double, c_ulonglong]),
     "bdg_mesh_set_bctype": (c_int, [_P, _P, c_int]),

@@ -64,6 +64,20 @@ int bdg_mesh_write(const bdg_mesh* mesh, const char* gmsh_path) {
     });
 }
 
+int bdg_mesh_write_cache(const bdg_mesh* mesh, const char* cache_path) {
+    return guard([&] {
+        if (!mesh || !cache_path) throw bdg_detail::arg_error("bdg_mesh_write_cache: NULL argument");
+        mesh->mgr.writeCache(cache_path);
+    });
+}
+
+int bdg_mesh_read_cache(bdg_mesh* mesh, const char* cache_path) {
+    return guard([&] {
+        if (!mesh || !cache_path) throw bdg_detail::arg_error("bdg_mesh_read_cache: NULL argument");
+        mesh->mgr.readCache(cache_path);
+    });
+}
+
 int bdg_mesh_build(bdg_mesh* mesh, const int* etov, int K, const double* vert, int Nv, int dim) {
     return guard([&] {
         if (!mesh || !etov || !vert || K < 1 || Nv < 3) throw bdg_detail::arg_error("bdg_mesh_build: bad argument");

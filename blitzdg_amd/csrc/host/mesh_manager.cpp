@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <numeric>
@@ -159,6 +160,102 @@ void MeshManager::writeMesh(const std::string& gmshOutputFile) const {
         std::fprintf(f, "%d 2 2 1 1 %d %d %d\n", k + 1, EToV(3 * k) + 1, EToV(3 * k + 1) + 1, EToV(3 * k + 2) + 1);
     std::fprintf(f, "$EndElements\n");
     if (std::fclose(f) != 0) throw std::runtime_error("Write failed for mesh file: " + gmshOutputFile);
+}
+
+namespace {
+
+constexpr char kCacheMagic[8] = {'B', 'D', 'G', 'M', 'E', 'S', 'H', '1'};
+constexpr std::uint32_t kCacheVersion = 1;
+
+struct CacheHeader {
+    char magic[8];
+    std::uint32_t version, dim, numFaces, reserved;
+    std::uint64_t numVerts, numElements;
+    std::uint64_t nVert, nEToV, nEToE, nEToF, nBC, nEPart, nVPart; // entries of each table
+};
+
+std::uint64_t fnv1a(std::uint64_t h, const void* data, std::size_t bytes) {
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (std::size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 1099511628211ULL; }
+    return h;
+}
+
+template <typename V>
+void putTable(std::FILE* f, const V& v, std::uint64_t& sum) {
+    const std::size_t bytes = static_cast<std::size_t>(v.size()) * sizeof(v[0]);
+    if (bytes && std::fwrite(&v[0], 1, bytes, f) != bytes) throw std::runtime_error("mesh cache: short write");
+    if (bytes) sum = fnv1a(sum, &v[0], bytes);
+}
+
+template <typename V>
+void getTable(std::FILE* f, V& v, std::uint64_t n, std::uint64_t& sum) {
+    if (n > 2000000000ULL) throw std::runtime_error("mesh cache: table size out of range");
+    v.resizeUninitialized(static_cast<index_type>(n));
+    const std::size_t bytes = static_cast<std::size_t>(n) * sizeof(v[0]);
+    if (bytes && std::fread(&v[0], 1, bytes, f) != bytes) throw std::runtime_error("mesh cache: file is truncated");
+    if (bytes) sum = fnv1a(sum, &v[0], bytes);
+}
+
+} // namespace
+
+void MeshManager::writeCache(const std::string& cacheFile) const {
+    std::FILE* f = std::fopen(cacheFile.c_str(), "wb");
+    if (!f) throw std::runtime_error("Unable to open mesh cache for writing: " + cacheFile);
+    CacheHeader h{};
+    std::memcpy(h.magic, kCacheMagic, 8);
+    h.version = kCacheVersion; h.dim = static_cast<std::uint32_t>(Dim); h.numFaces = static_cast<std::uint32_t>(NumFaces);
+    h.numVerts = static_cast<std::uint64_t>(NumVerts); h.numElements = static_cast<std::uint64_t>(NumElements);
+    h.nVert = Vert.size(); h.nEToV = EToV.size(); h.nEToE = EToE.size(); h.nEToF = EToF.size(); h.nBC = BCType.size();
+    h.nEPart = ElementPartitionMap.size(); h.nVPart = VertexPartitionMap.size();
+    std::uint64_t sum = fnv1a(14695981039346656037ULL, &h, sizeof h);
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    try {
+        if (!ok) throw std::runtime_error("mesh cache: short write");
+        putTable(f, Vert, sum); putTable(f, EToV, sum); putTable(f, EToE, sum); putTable(f, EToF, sum);
+        putTable(f, BCType, sum); putTable(f, ElementPartitionMap, sum); putTable(f, VertexPartitionMap, sum);
+        if (std::fwrite(&sum, sizeof sum, 1, f) != 1) throw std::runtime_error("mesh cache: short write");
+    } catch (...) {
+        std::fclose(f);
+        throw;
+    }
+    if (std::fclose(f) != 0) throw std::runtime_error("Write failed for mesh cache: " + cacheFile);
+}
+
+void MeshManager::readCache(const std::string& cacheFile) {
+    std::FILE* f = std::fopen(cacheFile.c_str(), "rb");
+    if (!f) throw std::runtime_error("Unable to open mesh cache: " + cacheFile);
+    MeshManager m; // filled completely and checked before this object is touched
+    try {
+        CacheHeader h{};
+        if (std::fread(&h, sizeof h, 1, f) != 1 || std::memcmp(h.magic, kCacheMagic, 8) != 0)
+            throw std::runtime_error("not a blitzdg mesh cache: " + cacheFile);
+        if (h.version != kCacheVersion) throw std::runtime_error("mesh cache: unsupported version");
+        if (h.numFaces != 3 || (h.dim != 2 && h.dim != 3) || h.numVerts < 3 || h.numVerts > 2000000000ULL || h.numElements < 1 ||
+            h.numElements > 600000000ULL)
+            throw std::runtime_error("mesh cache: header out of range");
+        const std::uint64_t K = h.numElements, faces = 3 * K;
+        if (h.nVert != h.numVerts * h.dim || h.nEToV != faces || h.nEToE != faces || h.nEToF != faces || h.nBC != faces ||
+            (h.nEPart != 0 && h.nEPart != K) || (h.nVPart != 0 && h.nVPart != h.numVerts))
+            throw std::runtime_error("mesh cache: table sizes do not fit the header");
+        std::uint64_t sum = fnv1a(14695981039346656037ULL, &h, sizeof h), stored = 0;
+        m.Dim = static_cast<index_type>(h.dim); m.NumFaces = 3;
+        m.NumVerts = static_cast<index_type>(h.numVerts); m.NumElements = static_cast<index_type>(K);
+        getTable(f, m.Vert, h.nVert, sum); getTable(f, m.EToV, h.nEToV, sum); getTable(f, m.EToE, h.nEToE, sum);
+        getTable(f, m.EToF, h.nEToF, sum); getTable(f, m.BCType, h.nBC, sum);
+        getTable(f, m.ElementPartitionMap, h.nEPart, sum); getTable(f, m.VertexPartitionMap, h.nVPart, sum);
+        if (std::fread(&stored, sizeof stored, 1, f) != 1) throw std::runtime_error("mesh cache: file is truncated");
+        if (stored != sum) throw std::runtime_error("mesh cache: checksum mismatch (corrupted file): " + cacheFile);
+        for (std::uint64_t i = 0; i < faces; ++i) {
+            const index_type v = m.EToV[static_cast<index_type>(i)], e = m.EToE[static_cast<index_type>(i)], ff = m.EToF[static_cast<index_type>(i)];
+            if (v < 0 || v >= m.NumVerts || e < 0 || e >= m.NumElements || ff < 0 || ff > 2)
+                throw std::runtime_error("mesh cache: index out of range");
+        }
+    } catch (...) {
+        std::fclose(f);
+        throw;
+    }
+    std::fclose(f);
+    *this = std::move(m);
 }
 
 void MeshManager::readVertices(const std::string& vertFile) {

@@ -60,6 +60,14 @@ class MeshManager:
         """Gmsh 2.2 ASCII of the triangles (the format readMesh takes)."""
         check(lib.bdg_mesh_write(self._h, str(gmshOutputFile).encode()))
 
+    def writeCache(self, cacheFile):
+        """Binary cache of the mesh with its connectivity, BC table and partition maps (one checksummed file)."""
+        check(lib.bdg_mesh_write_cache(self._h, str(cacheFile).encode()))
+
+    def readCache(self, cacheFile):
+        """Restores a mesh written by writeCache without reading ASCII or rebuilding connectivity."""
+        check(lib.bdg_mesh_read_cache(self._h, str(cacheFile).encode()))
+
     def buildMesh(self, EToV, Vert):
         """EToV: (K, 3) vertex ids (any numeric dtype, as the reference accepts float64);
         Vert: (Nv, 2|3) coordinates."""

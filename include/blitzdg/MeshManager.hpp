@@ -35,6 +35,12 @@ public:
     /// Writes the triangles as Gmsh 2.2 ASCII (two tags per element, coordinates with 17 significant
     /// digits) -- the format readMesh takes; not in the reference, which only reads.
     void writeMesh(const std::string& gmshOutputFile) const;
+    /// Binary cache of everything this class holds (vertices, EToV, EToE, EToF, BCType, partition maps): one file,
+    /// little-endian, checksummed. readCache restores the object without reading ASCII or rebuilding connectivity (the
+    /// step before the hot path at 10^6-10^7 elements); it refuses a file whose magic, version, sizes,
+    /// index ranges or checksum do not fit. Not in the reference, which re-reads the .msh file every run.
+    void writeCache(const std::string& cacheFile) const;
+    void readCache(const std::string& cacheFile);
     /// Reads whitespace/comma separated vertex table (rows of Dim reals).
     void readVertices(const std::string& vertFile);
     /// Reads element-to-vertex table (rows of NumFaces 0-based vertex ids).

@@ -80,6 +80,10 @@ int bdg_mesh_create(bdg_mesh** out);
 void bdg_mesh_destroy(bdg_mesh* mesh);
 int bdg_mesh_read(bdg_mesh* mesh, const char* gmsh_path);                 /* readMesh   */
 int bdg_mesh_write(const bdg_mesh* mesh, const char* gmsh_path);          /* Gmsh 2.2 ASCII, what readMesh takes */
+/* binary cache of a mesh with its connectivity, BC table and partition maps (MeshManager::writeCache / readCache; the
+ * reference has none: SURVEY 8f.2). read_cache refuses files whose magic, version, sizes, index ranges or checksum do not fit. */
+int bdg_mesh_write_cache(const bdg_mesh* mesh, const char* cache_path);
+int bdg_mesh_read_cache(bdg_mesh* mesh, const char* cache_path);
 int bdg_mesh_build(bdg_mesh* mesh, const int* etov, int num_elements,     /* buildMesh  */
                    const double* vert, int num_verts, int dim);
 int bdg_mesh_build_box(bdg_mesh* mesh, int nx, int ny, double x0, double x1, double y0, double y1,

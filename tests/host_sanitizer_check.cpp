@@ -19,6 +19,28 @@ int main(int argc, char** argv) {
     m.writeMesh("/tmp/asan_box.msh");
     MeshManager m2;
     m2.readMesh("/tmp/asan_box.msh");
+    {   // binary cache: round trip, then a truncated and a corrupted copy (both must throw, under the sanitizers)
+        m.writeCache("/tmp/asan_box.bdgmesh");
+        MeshManager c;
+        c.readCache("/tmp/asan_box.bdgmesh");
+        if (c.get_NumElements() != m.get_NumElements() || c.get_EToE()[5] != m.get_EToE()[5] ||
+            c.get_ElementPartitionMap().size() != m.get_ElementPartitionMap().size())
+            return 3;
+        std::FILE* f = std::fopen("/tmp/asan_box.bdgmesh", "rb");
+        std::vector<char> raw(1 << 20);
+        const size_t n = std::fread(raw.data(), 1, raw.size(), f);
+        std::fclose(f);
+        int refused = 0;
+        for (int variant = 0; variant < 2; ++variant) {
+            std::vector<char> bad(raw.begin(), raw.begin() + (variant == 0 ? n / 2 : n));
+            if (variant == 1) bad[n / 3] ^= 0x21;
+            f = std::fopen("/tmp/asan_bad.bdgmesh", "wb");
+            std::fwrite(bad.data(), 1, bad.size(), f);
+            std::fclose(f);
+            try { c.readCache("/tmp/asan_bad.bdgmesh"); } catch (const std::exception&) { ++refused; }
+        }
+        if (refused != 2) return 4;
+    }
     for (int order : {1, 2, 3, 5, 8}) {
         TriangleNodesProvisioner nodes(order, m2);
         nodes.buildFilter(0.9 * order, order < 2 ? 2 : order);
