@@ -359,6 +359,8 @@ def main():
     for order in (2, 4, 6):
         rhs4_case(f"coarse_box_N{order}", coarse, order)
     rhs4_case("box6x5_shuffled_N3", shuffled, 3)
+    rhs4_case("box6x5_shuffled_N5", shuffled, 5)  # N = 5, 7: the state-once kernel with sources and tracer (round 2)
+    rhs4_case("box6x5_shuffled_N7", shuffled, 7)
     rhs4_case("box2x2_N8", box, 8)
     rhsC_case("coarse_box_N3", coarse, 3)
     rhsC_case("box6x5_shuffled_N6", shuffled, 6)

@@ -149,7 +149,8 @@ def test_advec1d_oracle_matches_host_plumbing_and_converges():
     assert errs[0] / errs[1] > 8, errs
 
 
-RHS4_CASES = ["coarse_box_N2", "coarse_box_N4", "coarse_box_N6", "box6x5_shuffled_N3", "box2x2_N8"]
+RHS4_CASES = ["coarse_box_N2", "coarse_box_N4", "coarse_box_N6", "box6x5_shuffled_N3", "box6x5_shuffled_N5",
+              "box6x5_shuffled_N7", "box2x2_N8"]
 
 
 @pytest.mark.parametrize("case", RHS4_CASES)

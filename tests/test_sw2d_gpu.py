@@ -374,7 +374,8 @@ def test_config5_high_order_n8_steppers_vs_oracle():
 
 
 # ---------------------------------------------------------------- variant D (tracer + sources)
-RHS4_CASES = ["coarse_box_N2", "coarse_box_N4", "coarse_box_N6", "box6x5_shuffled_N3", "box2x2_N8"]
+RHS4_CASES = ["coarse_box_N2", "coarse_box_N4", "coarse_box_N6", "box6x5_shuffled_N3", "box6x5_shuffled_N5",
+              "box6x5_shuffled_N7", "box2x2_N8"]
 
 
 def _load4(case):
