@@ -97,6 +97,10 @@ struct StageParams {
 __device__ __forceinline__ double sponge_relax(double x, double sigma) {
     return sigma != 0.0 ? x / (1.0 + sigma * x * x) : x;
 }
+// The same without the test (x / (1 + 0 x^2) is x): for fully unrolled one-lane-per-element bodies, where a run-time test
+// per value splits the kernel's one scheduling region and everything held in scalar registers is hoisted and spilled
+// (DESIGN.md 3.6). Costs a division per value also when sigma is 0: used by the cross-check kernels only.
+__device__ __forceinline__ double sponge_relax_no_test(double x, double sigma) { return x / (1.0 + sigma * x * x); }
 
 template <int N, int MODE, bool FILTER>
 __global__ __launch_bounds__(256) void sw2d_stage_kernel(const StageParams p) {
@@ -284,8 +288,8 @@ __global__ __launch_bounds__(256) void sw2d_stage_kernel(const StageParams p) {
 #pragma unroll
         for (int i = 0; i < Np; ++i) {
             o[i * ld] = a * qb[i * ld] + b * h[i] + c * R1[i];
-            o[plane + i * ld] = sponge_relax(a * qb[plane + i * ld] + b * hu[i] + c * R2[i], p.sponge);
-            o[2 * plane + i * ld] = sponge_relax(a * qb[2 * plane + i * ld] + b * hv[i] + c * R3[i], p.sponge);
+            o[plane + i * ld] = sponge_relax_no_test(a * qb[plane + i * ld] + b * hu[i] + c * R2[i], p.sponge);
+            o[2 * plane + i * ld] = sponge_relax_no_test(a * qb[2 * plane + i * ld] + b * hv[i] + c * R3[i], p.sponge);
         }
     }
 }
