@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
 
     constexpr int IMAGE = O::DOUBLES + (NFILT ? MT * KV * 64 : 0); // [+ Filter tiles (r, t)]
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < IMAGE; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    stage_image<IMAGE, 256>(sOps, p.opsAffine);
     __syncthreads();
     // this wave's state tile; indexed through sOps so that the accesses stay LDS instructions (a generic pointer
     // would turn them into flat_load / flat_store, which also wait for every outstanding global load)
@@ -624,8 +624,7 @@ __global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StagePar
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
 
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
-    __syncthreads();
+    bool staged = false; // the operator image is staged AFTER the first tile's loads are requested (below)
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
     const int c = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)); // field of this wave
@@ -694,6 +693,11 @@ __global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StagePar
             sendRec[0] = p.haloSendOf[b3];
             sendRec[1] = p.haloSendOf[b3 + 1];
             sendRec[2] = p.haloSendOf[b3 + 2];
+        }
+        if (!staged) { // (every workgroup has a first tile: the grid is the tile count; the flag is workgroup-uniform)
+            stage_image<O::DOUBLES, 192>(sOps, p.opsAffine);
+            __syncthreads();
+            staged = true;
         }
 
         mfma_acc_t acc[MT];

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
     constexpr int IMAGE = L::IMAGE, OFF_F = O::DOUBLES;
 
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < IMAGE; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    stage_image<IMAGE, 256>(sOps, p.opsAffine);
     __syncthreads();
     const int sBase = IMAGE + static_cast<int>(threadIdx.x >> 6) * L::TILE_DOUBLES + static_cast<int>(threadIdx.x & 15u);
 

@@ -20,6 +20,30 @@
 
 namespace bdg_dev {
 
+// Operator image -> LDS at the start of a workgroup: every thread requests ALL its 16-byte pieces before it stores the
+// first (one round trip to L2 instead of one per piece: a plain copy loop compiles to load, wait, store per iteration, 25-33
+// round trips for the 50 KB image of N = 8 -- 5 us at the start of every launch, and of every partition-boundary strip).
+typedef double bdg_f64x2 __attribute__((ext_vector_type(2)));
+template <int COUNT, int THREADS>
+__device__ __attribute__((noinline)) void stage_image(double* __restrict__ lds, const double* __restrict__ src) {
+    static_assert(COUNT % 2 == 0, "operator images are whole 64-double tiles");
+    constexpr int PAIRS = COUNT / 2, STEPS = (PAIRS + THREADS - 1) / THREADS;
+    const bdg_f64x2* __restrict__ s2 = reinterpret_cast<const bdg_f64x2*>(src);
+    bdg_f64x2* __restrict__ d2 = reinterpret_cast<bdg_f64x2*>(lds);
+    bdg_f64x2 v[STEPS];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int at = i * THREADS + static_cast<int>(threadIdx.x);
+        if (at < PAIRS) v[i] = s2[at];
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+        const int at = i * THREADS + static_cast<int>(threadIdx.x);
+        if (at < PAIRS) d2[at] = v[i];
+    }
+}
+
+
 typedef double mfma_acc_t __attribute__((ext_vector_type(4)));
 
 #ifndef BDG_MFMA_WAVES
@@ -48,7 +72,7 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
     constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN, MT = O::MT, KV = O::KV, KS = O::KS;
 
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    stage_image<O::DOUBLES, 256>(sOps, p.opsAffine);
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
@@ -294,7 +318,7 @@ __global__ __launch_bounds__(256, BDG_MFMA2_WAVES) void sw2d_stage_mfma2_kernel(
     constexpr int IMAGE = O::DOUBLES + (PHYS != 0 ? MT * KV * 64 : 0);
 
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < IMAGE; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    stage_image<IMAGE, 256>(sOps, p.opsAffine);
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
@@ -612,7 +636,7 @@ __global__ __launch_bounds__(256, 3) void sw2d_stage_mfma2_tracer_kernel(const S
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
 
     extern __shared__ double sOps[];
-    for (int t = threadIdx.x; t < O::DOUBLES; t += blockDim.x) sOps[t] = p.opsAffine[t];
+    stage_image<O::DOUBLES, 256>(sOps, p.opsAffine);
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
