@@ -264,7 +264,21 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
     const int wrefAt = OPSLDS ? O::tiles(ncb, fb) * 64 : 0;
     if constexpr (OPSLDS) {
         const int n = O::tiles(ncb, fb) * 64;
-        for (int t = threadIdx.x; t < n; t += blockDim.x) sOps[t] = p.ops[t];
+        // eight 16-byte pieces per thread in flight at a time (a plain copy loop is load, wait, store per iteration: 25 round
+        // trips to L2 for a 50 KB image at the start of every workgroup)
+        typedef double cbdg_f64x2 __attribute__((ext_vector_type(2)));
+        const cbdg_f64x2* __restrict__ s2 = reinterpret_cast<const cbdg_f64x2*>(p.ops);
+        cbdg_f64x2* __restrict__ d2 = reinterpret_cast<cbdg_f64x2*>(sOps);
+        const int pairs = n / 2, nthreads = static_cast<int>(blockDim.x);
+        for (int b = threadIdx.x; b < pairs; b += 8 * nthreads) {
+            cbdg_f64x2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (b + i * nthreads < pairs) v[i] = s2[b + i * nthreads];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (b + i * nthreads < pairs) d2[b + i * nthreads] = v[i];
+        }
     }
     for (int t = threadIdx.x; t < 16 * ncb; t += blockDim.x) sOps[wrefAt + t] = p.cubWref ? p.cubWref[t] : 0.0;
     __syncthreads();
