@@ -105,6 +105,11 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
 
     constexpr int IMAGE = O::DOUBLES + (NFILT ? MT * KV * 64 : 0); // [+ Filter tiles (r, t)]
+    // Per-node geometry and the halo form at N = 8: nothing of the NEXT tile is requested ahead (its state, traces, indices
+    // and face geometry are 230 registers; with them these forms spilled 125-170 registers, and a spilled register's reload
+    // drains the memory pipeline every time: 0.96 ms per stage at C5 with per-node geometry, 0.41 ms without the prefetch).
+    // The tile's own data is requested at its top instead: one exposed round trip per tile.
+    constexpr bool PF = !((NODAL || HALO) && MT >= 3 && KV >= 12);
     extern __shared__ double sOps[];
     stage_image<IMAGE, 256>(sOps, p.opsAffine);
     __syncthreads();
@@ -243,18 +248,20 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
     unsigned k = elementOf(tile, live);
     double qB[3][KV], geo[13], hP[3][KF], huP[3][KF], hvP[3][KF];
     int fidx[3][KF];
-    loadIndices(k, fidx);
-#pragma unroll
-    for (int t = 0; t < KV; ++t) loadStateRow(k, t, qB);
-    loadGeometry(k, geo);
-#pragma unroll
-    for (int f = 0; f < 3; ++f) loadTraces(f, fidx, hP, huP, hvP);
-    // nodal geometry of the first tile: all face normals / scales
     double fnx[3][KF], fny[3][KF], fsc[3][KF];
-    if constexpr (NODAL) {
+    auto loadTile = [&](unsigned kk) { // everything a tile needs before its first product
+        loadIndices(kk, fidx);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) loadFaceGeometry(f, k, fnx, fny, fsc);
-    }
+        for (int t = 0; t < KV; ++t) loadStateRow(kk, t, qB);
+        loadGeometry(kk, geo);
+#pragma unroll
+        for (int f = 0; f < 3; ++f) loadTraces(f, fidx, hP, huP, hvP);
+        if constexpr (NODAL) { // all face normals / scales
+#pragma unroll
+            for (int f = 0; f < 3; ++f) loadFaceGeometry(f, kk, fnx, fny, fsc);
+        }
+    };
+    if constexpr (PF) loadTile(k); // the first tile; the following ones are requested piece by piece a tile ahead
 
 #ifdef BDG_PHASE_CLOCK
     stamp = __builtin_readcyclecounter();
@@ -265,6 +272,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         const bool more = tile + tileStep < tileEnd;
         bool liveN = false;
         const unsigned kN = more ? elementOf(tile + tileStep, liveN) : k;
+        if constexpr (!PF) loadTile(k);
         // next tile, requested piece by piece below as this tile's registers fall free
         double qN[3][KV], geoN[13], hPN[3][KF], huPN[3][KF], hvPN[3][KF];
         int fidxN[3][KF];
@@ -363,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                 lamF = 0.0;
                 // this face's '+' traces are dead: request the next tile's (requesting all three faces in the last k-steps
                 // instead, so that they never wait for their indices, was slower: too many requests at once)
-                loadTraces(f, fidxN, hPN, huPN, hvPN);
-                if constexpr (NODAL) loadFaceGeometry(f, kN, fnxN, fnyN, fscN);
+                if constexpr (PF) loadTraces(f, fidxN, hPN, huPN, hvPN);
+                if constexpr (NODAL && PF) loadFaceGeometry(f, kN, fnxN, fnyN, fscN);
             }
         };
         constexpr int FACE_ITEMS = 3 * KF, PER_STEP = (FACE_ITEMS + KV - 1) / KV;
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             // s = (hu, hv, F2, G2, G3) (their values are formed again in every pass: a few dozen vector instructions against
             // 10 matrix instructions per k-step), then the block's rows R_c = -(rx Dr F_c + sx Ds F_c + ry Dr G_c + sy Ds G_c)
             // with the metric rows of the block's own nodes. The next tile's state is requested during the last pass.
-            loadIndices(kN, fidxN);
+            if constexpr (PF) loadIndices(kN, fidxN);
             constexpr int STEPS = MT * KV, PER = (FACE_ITEMS + STEPS - 1) / STEPS;
 #pragma unroll
             for (int r = 0; r < MT; ++r) {
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                 for (int t = 0; t < KV; ++t) {
                     double fl[6];
                     volumeOperands(t, fl);
-                    if (r == MT - 1) loadStateRow(kN, t, qN);
+                    if (PF && r == MT - 1) loadStateRow(kN, t, qN);
 #pragma unroll
                     for (int it = (r * KV + t) * PER; it < (r * KV + t + 1) * PER; ++it)
                         if (it < FACE_ITEMS) faceNode(it / KF, it % KF);
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         }
 
         BDG_STAMP(13) // volume term (rest)
-        loadGeometry(kN, geoN);
+        if constexpr (PF) loadGeometry(kN, geoN);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- stage update / output of the rows of block r: node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3);
@@ -579,20 +587,22 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         tile += tileStep;
         k = kN;
         live = liveN;
+        if constexpr (PF) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int t = 0; t < KV; ++t) qB[c][t] = qN[c][t];
+                for (int t = 0; t < KV; ++t) qB[c][t] = qN[c][t];
 #pragma unroll
-        for (int i = 0; i < 13; ++i) geo[i] = geoN[i];
+            for (int i = 0; i < 13; ++i) geo[i] = geoN[i];
 #pragma unroll
-        for (int f = 0; f < 3; ++f)
+            for (int f = 0; f < 3; ++f)
 #pragma unroll
-            for (int tf = 0; tf < KF; ++tf) {
-                fidx[f][tf] = fidxN[f][tf];
-                hP[f][tf] = hPN[f][tf]; huP[f][tf] = huPN[f][tf]; hvP[f][tf] = hvPN[f][tf];
-                if constexpr (NODAL) { fnx[f][tf] = fnxN[f][tf]; fny[f][tf] = fnyN[f][tf]; fsc[f][tf] = fscN[f][tf]; }
-            }
+                for (int tf = 0; tf < KF; ++tf) {
+                    fidx[f][tf] = fidxN[f][tf];
+                    hP[f][tf] = hPN[f][tf]; huP[f][tf] = huPN[f][tf]; hvP[f][tf] = hvPN[f][tf];
+                    if constexpr (NODAL) { fnx[f][tf] = fnxN[f][tf]; fny[f][tf] = fnyN[f][tf]; fsc[f][tf] = fscN[f][tf]; }
+                }
+        }
 
     }
 #ifdef BDG_PHASE_CLOCK

@@ -77,6 +77,8 @@ def test_no_matrix_instruction_overwrites_an_operand_it_is_still_reading(assembl
                                  text))
         plain = {k: int(v) for k, v in spills.items() if "ELb0ELb0ELb0E" in k}
         assert len(plain) == 3 and not any(plain.values()), plain
+        # the per-node-geometry and halo forms give up the next-tile prefetch at this order for the same reason
+        assert len(spills) >= 9 and max(int(v) for v in spills.values()) <= 16, spills
 
 
 def test_unrolled_kernels_keep_their_one_scheduling_region(assembly):
