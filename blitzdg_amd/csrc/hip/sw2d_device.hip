@@ -438,12 +438,17 @@ struct bdg_sw2d {
                 ph.slope = -1.0; ph.dragSign = 1.0;   // swhelpers/rhs.py:300-309
             }
             p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
-            // state-once schedule where it exists (sw2d_mfma3src_kernel.hpp: N = 5, 6, 7, with and without the tracer;
+            // state-once schedule where it exists (sw2d_mfma3src_kernel.hpp: N = 5, 6, 7 with and without the tracer, N = 8 three fields;
             // BDG_SW2D_SOURCES_TWO_WAVE=1 keeps the two-waves-per-SIMD kernels below for A/B runs and cross-checks)
             const bool stateOnceSrc = !std::getenv("BDG_SW2D_SOURCES_TWO_WAVE");
             if (stateOnceSrc && kt->mfma3SrcFields >= nf && !std::getenv("BDG_SW2D_TRACER_PASS") &&
                 static_cast<long long>(nf) * Np * ld * 8 <= 4294967295LL) {
                 hipCheck(kt->stageMfma2Src(mode, p, ph, nf == 4 ? 5 : 4, st), what);
+            } else if (stateOnceSrc && kt->mfma3SrcFields == 3 && nf == 4 && static_cast<long long>(3) * Np * ld * 8 <= 4294967295LL) {
+                // N = 8: three conserved fields with sources on the state-once schedule, the tracer in its own pass
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 4, st), what);
+                p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 1, st), what);
             } else if (nf == 4 && kt->mfmaMT <= 2 && !std::getenv("BDG_SW2D_TRACER_PASS")) {
                 hipCheck(kt->stageMfma2Src(mode, p, ph, 3, st), what);     // N <= 6: the tracer rides in the same pass
             } else {

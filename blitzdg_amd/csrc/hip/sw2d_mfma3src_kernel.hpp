@@ -34,6 +34,9 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
     using L = Mfma3SrcLds<N, TRACER>;
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF, NF = L::NF;
     constexpr int IMAGE = L::IMAGE, OFF_F = O::DOUBLES;
+    // N = 8: nothing of the next tile is requested ahead (it would not fit the registers, and a spilled register's reload
+    // drains the memory pipeline); the tile's own data is requested at its top: one exposed round trip per tile
+    constexpr bool PF = KV < 12;
 
     extern __shared__ double sOps[];
     stage_image<IMAGE, 256>(sOps, p.opsAffine);
@@ -108,12 +111,15 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
     unsigned k = elementOf(tile, live);
     double qB[NF][KV], srcB[3][KV], geo[13], trP[NF][3][KF];
     int fidx[3][KF];
-    loadIndices(k, fidx);
+    auto loadTile = [&](unsigned kk) { // everything a tile needs before its first product
+        loadIndices(kk, fidx);
 #pragma unroll
-    for (int t = 0; t < KV; ++t) loadStateRow(k, t, qB, srcB);
-    loadGeometry(k, geo);
+        for (int t = 0; t < KV; ++t) loadStateRow(kk, t, qB, srcB);
+        loadGeometry(kk, geo);
 #pragma unroll
-    for (int f = 0; f < 3; ++f) loadTraces(f, fidx, trP);
+        for (int f = 0; f < 3; ++f) loadTraces(f, fidx, trP);
+    };
+    if constexpr (PF) loadTile(k); // the first tile; the following ones are requested piece by piece a tile ahead
 
 #pragma unroll 1
     for (;;) {
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         const unsigned kN = more ? elementOf(tile + tileStep, liveN) : k;
         double qN[NF][KV], srcN[3][KV], geoN[13], trN[NF][3][KF];
         int fidxN[3][KF];
+        if constexpr (!PF) loadTile(k);
 
         // ---- own state into the wave's LDS tile (face traces and the update read it back from there)
 #pragma unroll
@@ -217,19 +224,19 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
 #pragma unroll
                     for (int c = 0; c < NF; ++c) sF[f][c][t2] = hfs * (eF[c][t2] - lam * dF[c][t2]);
                 lamF = 0.0;
-                loadTraces(f, fidxN, trN); // this face's '+' traces are dead: request the next tile's
+                if constexpr (PF) loadTraces(f, fidxN, trN); // this face's '+' traces are dead: request the next tile's
             }
         };
         constexpr int FACE_ITEMS = 3 * KF, PER_STEP = (FACE_ITEMS + KV - 1) / KV;
 
-        loadIndices(kN, fidxN);
+        if constexpr (PF) loadIndices(kN, fidxN);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int OLD_EARLY = (MT > 1 ? 4 * (MT - 1) : 0) < KV ? (MT > 1 ? 4 * (MT - 1) : 0) : KV;
 #pragma unroll
         for (int t = 0; t < KV; ++t) {
             double ab[2 * NF], ss[2];
             volumeOperands(t, ab, ss);
-            loadStateRow(kN, t, qN, srcN);
+            if constexpr (PF) loadStateRow(kN, t, qN, srcN);
             if (t >= KV - OLD_EARLY) loadOldRow(t - (KV - OLD_EARLY));
 #pragma unroll
             for (int it = t * PER_STEP; it < (t + 1) * PER_STEP; ++it)
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         }
 #pragma unroll
         for (int t = OLD_EARLY; t < KV; ++t) loadOldRow(t);
-        loadGeometry(kN, geoN);
+        if constexpr (PF) loadGeometry(kN, geoN);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- stage update / output of the rows of block r (node m = 4 t + q is accumulator row 16 (t >> 2) + q + 4 (t & 3))
@@ -305,6 +312,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         tile += tileStep;
         k = kN;
         live = liveN;
+        if constexpr (!PF) continue;
 #pragma unroll
         for (int t = 0; t < KV; ++t) {
 #pragma unroll

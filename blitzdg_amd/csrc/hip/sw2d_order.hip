@@ -28,10 +28,10 @@ constexpr bool kNoUnrolledSources = BDG_ORDER > 4;
 constexpr bool kNoStream = BDG_ORDER > 5;
 // The matrix-core source-term / tracer / variant-B kernels exist from this order up.
 constexpr bool kMfmaSources = BDG_ORDER >= 5;
-// state-once kernel with sources (sw2d_mfma3src_kernel.hpp), with the tracer too, at N = 5, 6, 7 (N = 7 with tracer: 501-512
-// registers, 3 spilled in the combine form and still 1.9 times the two-wave kernels); N = 8 does not fit: operators + F'
-// tiles + four waves' state tiles exceed 160 KB of LDS, and three fields alone already take 488 registers
-constexpr int kMfma3SrcFields = (BDG_ORDER >= 5 && BDG_ORDER <= 7) ? 4 : 0;
+// state-once kernel with sources (sw2d_mfma3src_kernel.hpp): with the tracer too at N = 5, 6, 7 (N = 7 with tracer: 501-512
+// registers, 3 spilled in the combine form and still 1.9 times the two-wave kernels); three fields at N = 8, without the
+// next-tile prefetch (registers) -- four fields' state tiles + operators + F' tiles would exceed 160 KB of LDS there
+constexpr int kMfma3SrcFields = (BDG_ORDER >= 5 && BDG_ORDER <= 7) ? 4 : (BDG_ORDER == 8 ? 3 : 0);
 
 // Rolled kernels. FIELDS = 1 (three waves per 64 elements, one field each) exists for every
 // order; FIELDS = 3 (all fields per lane) only where 3*Np accumulators fit (N <= 6).

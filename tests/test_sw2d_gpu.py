@@ -963,7 +963,7 @@ def test_tracer_output_field_and_vtu(coarse_mesh, tmp_path):
         sw2d.Sw2dSolver(nodes=nodes).outputTracer()
 
 
-@pytest.mark.parametrize("order,nx,ny,fields", [(5, 37, 29, 4), (6, 30, 41, 4), (6, 21, 19, 3), (7, 23, 17, 3), (7, 19, 26, 4)])
+@pytest.mark.parametrize("order,nx,ny,fields", [(5, 37, 29, 4), (6, 30, 41, 4), (6, 21, 19, 3), (7, 23, 17, 3), (7, 19, 26, 4), (8, 27, 22, 3), (8, 17, 23, 4)])
 def test_state_once_kernel_with_sources_and_tracer_on_many_tiles(order, nx, ny, fields, monkeypatch):
     """Variants C / D on the state-once schedule (sw2d_mfma3src_kernel.hpp: N = 5, 6, 7, with and without the tracer; the
     default there) with several tiles per wave, a ragged last tile, a shuffled element order, array-valued bed
