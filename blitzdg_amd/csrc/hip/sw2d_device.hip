@@ -369,7 +369,7 @@ struct bdg_sw2d {
                     ph.slope = 1.0; ph.dragSign = -1.0;
                     ph.H = vb.H; ph.obc = vb.obc; ph.lam = lamBuf.p; ph.spongeField = vb.sponge; ph.tide = vb.tide;
                     p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
-                    hipCheck(kt->stageMfma2Src(mode, p, ph, 2, st), what);
+                    hipCheck(kt->stageMfma2Src(mode, p, ph, variantBStateOnce() ? 6 : 2, st), what);
                 } else {
                     p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
                     hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 6, nullptr, st), what);
@@ -403,7 +403,7 @@ struct bdg_sw2d {
                 ph.slope = 1.0; ph.dragSign = -1.0;             // src/sw2d/main.cpp:461-478
                 ph.H = vb.H; ph.obc = vb.obc; ph.lam = lamBuf.p; ph.spongeField = vb.sponge; ph.tide = vb.tide;
                 p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
-                hipCheck(kt->stageMfma2Src(mode, p, ph, 2, st), what);
+                hipCheck(kt->stageMfma2Src(mode, p, ph, variantBStateOnce() ? 6 : 2, st), what);
             } else {
                 p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
                 hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 0, nullptr, st), what);
@@ -480,6 +480,12 @@ struct bdg_sw2d {
         } else {
             hipCheck(kt->stage(mode, filter, p, st), what);
         }
+    }
+    // variant B's stage kernel on the state-once schedule where it exists (sw2d_mfma3src_kernel.hpp, PHYS = 2);
+    // BDG_SW2D_SOURCES_TWO_WAVE=1 keeps the two-waves-per-SIMD kernel
+    bool variantBStateOnce() const {
+        return kt->mfma3SrcFields >= 3 && !std::getenv("BDG_SW2D_SOURCES_TWO_WAVE") &&
+               static_cast<long long>(3) * Np * ld * 8 <= 4294967295LL;
     }
     DevBuf<double> opsMfma2NodalFilter; // plain MfmaOps2 image + MT*KV Filter tiles
     bool nodalMfma = false;   // non-affine tables: matrix-core kernel (default) instead of the N <= 6 vector kernel

@@ -27,8 +27,14 @@ struct Mfma3SrcLds {
     static constexpr int DOUBLES = IMAGE + 4 * TILE_DOUBLES;
 };
 
-template <int N, int MODE, bool TRACER>
+// PHYS = 2: the surface term of the reference's variable-depth tidal driver (variant B, src/sw2d/main.cpp:340-368, as in
+// sw2d_stage_mfma2_kernel<N, MODE, 2>): depth traces H at both sides of a face node, open-boundary nodes (bit mask per
+// element) take the tide elevation, hydrostatic-reconstruction star states, the GLOBAL Lax-Friedrichs speed (a device
+// scalar reduced beforehand), sources with the depth gradient (slope = +1, dragSign = -1), and in combine steps the
+// per-node sponge coefficient. No tracer.
+template <int N, int MODE, bool TRACER, int PHYS = 1>
 __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const StageParams p, const PhysParams ph) {
+    static_assert(PHYS == 1 || (PHYS == 2 && !TRACER), "variant B has three fields");
     using E = Elem<N>;
     using O = MfmaOps2<N>;
     using L = Mfma3SrcLds<N, TRACER>;
@@ -66,6 +72,12 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                                  rsx = plane_rsrc(ph.sx ? ph.sx : p.ageo, ph.sx ? planeBytes : 0u),
                                  rsy = plane_rsrc(ph.sy ? ph.sy : p.ageo, ph.sy ? planeBytes : 0u),
                                  rfc = plane_rsrc(ph.fcor ? ph.fcor : p.ageo, ph.fcor ? planeBytes : 0u);
+    const __amdgpu_buffer_rsrc_t rH = plane_rsrc(PHYS == 2 ? ph.H : p.ageo, PHYS == 2 ? planeBytes : 0u),
+                                 robc = plane_rsrc(PHYS == 2 ? static_cast<const void*>(ph.obc) : static_cast<const void*>(p.ageo), PHYS == 2 ? ld4 : 0u),
+                                 rsp = plane_rsrc((PHYS == 2 && ph.spongeField) ? ph.spongeField : p.ageo,
+                                                  (PHYS == 2 && ph.spongeField) ? planeBytes : 0u);
+    const bool hasSp = PHYS == 2 && ph.spongeField != nullptr;
+    const double lamGlobal = PHYS == 2 ? *ph.lam : 0.0, tide = ph.tide;
     const bool hasF = ph.fcor != nullptr;
     const double cd = ph.cd, slope = ph.slope, dragSign = ph.dragSign, fconst = ph.fconst;
 
@@ -96,7 +108,8 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         for (int i = 0; i < 13; ++i) gg[i] = bld_f64(rgeo, kk * 8u, static_cast<unsigned>(i) * ld8);
     };
     // neighbour traces of face f (face node n = 4 tf + q); lanes beyond the face read node 0 of element 0 and ignore it
-    auto loadTraces = [&](int f, const int (&ix)[3][KF], double (&tr)[NF][3][KF]) {
+    // (PHYS = 2: also the depth at the node itself and at its neighbour, dep[0] = H-, dep[1] = H+)
+    auto loadTraces = [&](int f, unsigned kk, const int (&ix)[3][KF], double (&tr)[NF][3][KF], double (&dep)[2][3][KF]) {
 #pragma unroll
         for (int tf = 0; tf < KF; ++tf) {
             const int n = 4 * tf + static_cast<int>(q);
@@ -104,20 +117,26 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
             const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
 #pragma unroll
             for (int c = 0; c < NF; ++c) tr[c][f][tf] = bld_f64(rq, o8, static_cast<unsigned>(c) * planeBytes);
+            if constexpr (PHYS == 2) {
+                const int m = n < Nfp ? fmask_rt<N>(f, n) : 0;
+                dep[0][f][tf] = bld_f64(rH, (static_cast<unsigned>(m) * static_cast<unsigned>(ld) + kk) * 8u, 0u);
+                dep[1][f][tf] = bld_f64(rH, o8, 0u);
+            }
         }
     };
 
     bool live;
     unsigned k = elementOf(tile, live);
-    double qB[NF][KV], srcB[3][KV], geo[13], trP[NF][3][KF];
-    int fidx[3][KF];
+    double qB[NF][KV], srcB[3][KV], geo[13], trP[NF][3][KF], depP[2][3][KF];
+    int fidx[3][KF], btags = 0; // btags (PHYS = 2): bit f Nfp + n set = open-boundary node n of face f
     auto loadTile = [&](unsigned kk) { // everything a tile needs before its first product
         loadIndices(kk, fidx);
 #pragma unroll
         for (int t = 0; t < KV; ++t) loadStateRow(kk, t, qB, srcB);
         loadGeometry(kk, geo);
 #pragma unroll
-        for (int f = 0; f < 3; ++f) loadTraces(f, fidx, trP);
+        for (int f = 0; f < 3; ++f) loadTraces(f, kk, fidx, trP, depP);
+        if constexpr (PHYS == 2) btags = bld_i32(robc, kk * 4u, 0u);
     };
     if constexpr (PF) loadTile(k); // the first tile; the following ones are requested piece by piece a tile ahead
 
@@ -127,7 +146,8 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         const bool more = tile + tileStep < tileEnd;
         bool liveN = false;
         const unsigned kN = more ? elementOf(tile + tileStep, liveN) : k;
-        double qN[NF][KV], srcN[3][KV], geoN[13], trN[NF][3][KF];
+        double qN[NF][KV], srcN[3][KV], geoN[13], trN[NF][3][KF], depN[2][3][KF];
+        int btagsN = 0;
         int fidxN[3][KF];
         if constexpr (!PF) loadTile(k);
 
@@ -141,12 +161,14 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
             }
         __builtin_amdgcn_wave_barrier();
 
-        double oldv[NF][KV];
+        double oldv[NF][KV], spv[KV]; // spv (PHYS = 2, combine steps): the nodes' sponge coefficients (0 without a field)
         auto loadOldRow = [&](int t) {
             if constexpr (MODE != MODE_RHS) {
 #pragma unroll
                 for (int c = 0; c < NF; ++c)
                     oldv[c][t] = bld_f64(rold, row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(c) * planeBytes + static_cast<unsigned>(4 * t) * ld8);
+                if constexpr (PHYS == 2 && MODE == MODE_COMBINE)
+                    spv[t] = bld_f64(rsp, row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
             }
         };
         mfma_acc_t acc[NF][MT];
@@ -189,19 +211,42 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
             for (int c = 0; c < NF; ++c) eF[c][tf] = dF[c][tf] = 0.0;
             if (n < Nfp) {
                 const int m = fmask_rt<N>(f, n);
-                const double hM = sOps[sBase + m * 16], huM = sOps[sBase + (Np + m) * 16], hvM = sOps[sBase + (2 * Np + m) * 16];
-                const double hq = trP[0][f][tf];
+                const double hM0 = sOps[sBase + m * 16], huM0 = sOps[sBase + (Np + m) * 16], hvM0 = sOps[sBase + (2 * Np + m) * 16];
+                double hM = hM0, huM = huM0, hvM = hvM0, hq = trP[0][f][tf];
                 double huq = trP[1][f][tf], hvq = trP[2][f][tf];
-                if (fidx[f][tf] < 0) { // reflective wall: no normal flow
-                    const double un = huM * nxf + hvM * nyf;
-                    huq = huM - 2 * nxf * un;
-                    hvq = hvM - 2 * nyf * un;
+                if constexpr (PHYS == 2) { // as sw2d_stage_mfma2_kernel<N, MODE, 2> (src/sw2d/main.cpp:340-368)
+                    const double HM = depP[0][f][tf], HP = depP[1][f][tf];
+                    if ((btags >> (f * Nfp + n)) & 1) {   // open boundary (:348-353)
+                        huq = huM;
+                        hvq = hvM;
+                        hq = HM + tide;
+                    } else if (fidx[f][tf] < 0) {          // reflective wall (:340-345)
+                        const double un = huM * nxf + hvM * nyf;
+                        hq = hM;
+                        huq = huM - 2 * nxf * un;
+                        hvq = hvM - 2 * nyf * un;
+                    }
+                    const double bM = -HM, bP = -HP, mx = fmax(bP, bM);
+                    const double hMs = fmax(0.0, hM + bM - mx), hPs = fmax(0.0, hq + bP - mx);
+                    const double rMs = fast_rcp(hMs), rPs = fast_rcp(hPs);
+                    huM = hMs * (huM * rMs); hvM = hMs * (hvM * rMs);  // hMstar*(huM/hM), hM = hMstar
+                    huq = hPs * (huq * rPs); hvq = hPs * (hvq * rPs);
+                    hM = hMs;
+                    hq = hPs;
+                } else {
+                    if (fidx[f][tf] < 0) { // reflective wall: no normal flow
+                        const double un = huM * nxf + hvM * nyf;
+                        huq = huM - 2 * nxf * un;
+                        hvq = hvM - 2 * nyf * un;
+                    }
                 }
                 const double rM = fast_rcp(hM), rP = fast_rcp(hq);
                 const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
-                const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
-                const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
-                lamF = fmax(lamF, fmax(spdM, spdP));
+                if constexpr (PHYS != 2) {
+                    const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                    const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                    lamF = fmax(lamF, fmax(spdM, spdP));
+                }
                 const double prM = halfg * hM * hM, prP = halfg * hq * hq;
                 const double F2M = huM * uM + prM, G2M = huM * vM, G3M = hvM * vM + prM;
                 const double F2P = huq * uP + prP, G2P = huq * vP, G3P = hvq * vP + prP;
@@ -216,20 +261,24 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                 }
             }
             if (tf == KF - 1) { // the face is complete: its speed (the face's nodes sit in the 4 lanes q of this element)
-                double lam = fmax(lamF, __shfl_xor(lamF, 16));
-                lam = fmax(lam, __shfl_xor(lam, 32));
+                double lam = lamGlobal;
+                if constexpr (PHYS != 2) {
+                    lam = fmax(lamF, __shfl_xor(lamF, 16));
+                    lam = fmax(lam, __shfl_xor(lam, 32));
+                }
                 const double hfs = 0.5 * geo[10 + f];
 #pragma unroll
                 for (int t2 = 0; t2 < KF; ++t2)
 #pragma unroll
                     for (int c = 0; c < NF; ++c) sF[f][c][t2] = hfs * (eF[c][t2] - lam * dF[c][t2]);
                 lamF = 0.0;
-                if constexpr (PF) loadTraces(f, fidxN, trN); // this face's '+' traces are dead: request the next tile's
+                if constexpr (PF) loadTraces(f, kN, fidxN, trN, depN); // this face's '+' traces are dead: request the next tile's
             }
         };
         constexpr int FACE_ITEMS = 3 * KF, PER_STEP = (FACE_ITEMS + KV - 1) / KV;
 
         if constexpr (PF) loadIndices(kN, fidxN);
+        if constexpr (PF && PHYS == 2) btagsN = bld_i32(robc, kN * 4u, 0u);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int OLD_EARLY = (MT > 1 ? 4 * (MT - 1) : 0) < KV ? (MT > 1 ? 4 * (MT - 1) : 0) : KV;
 #pragma unroll
@@ -287,7 +336,8 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                         bst_f64(rout, vo, soff, own[c][e] + p.cb * n1);
                     } else {
                         const double val = p.ca * oldv[c][t] + p.cb * own[c][e] + p.cc * R;
-                        bst_f64(rout, vo, soff, (c == 1 || c == 2) ? sponge_relax(val, p.sponge) : val);
+                        const double sp = (PHYS == 2 && hasSp) ? spv[t] : p.sponge;
+                        bst_f64(rout, vo, soff, (c == 1 || c == 2) ? sponge_relax(val, sp) : val);
                     }
                 }
         };
@@ -322,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         }
 #pragma unroll
         for (int i = 0; i < 13; ++i) geo[i] = geoN[i];
+        btags = btagsN;
 #pragma unroll
         for (int f = 0; f < 3; ++f)
 #pragma unroll
@@ -329,6 +380,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                 fidx[f][tf] = fidxN[f][tf];
 #pragma unroll
                 for (int c = 0; c < NF; ++c) trP[c][f][tf] = trN[c][f][tf];
+                if constexpr (PHYS == 2) { depP[0][f][tf] = depN[0][f][tf]; depP[1][f][tf] = depN[1][f][tf]; }
             }
     }
 }

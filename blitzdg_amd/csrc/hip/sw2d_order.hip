@@ -354,7 +354,7 @@ hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer
     const unsigned waves = tracer == 1 ? 3u : static_cast<unsigned>(BDG_MFMA2_WAVES);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(waves, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
-    if (tracer == 4 || tracer == 5) { // state-once schedule with sources (and tracer)
+    if (tracer == 4 || tracer == 5 || tracer == 6) { // state-once schedule with sources (and tracer); 6: variant B
         if constexpr (kMfma3SrcFields == 0) return hipErrorNotSupported;
         else {
             if (tracer == 5 && kMfma3SrcFields < 4) return hipErrorNotSupported;
@@ -375,6 +375,7 @@ hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer
                     return launch(sw2d_stage_mfma3src_kernel<kN, MODE, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
                 else return hipErrorNotSupported;
             }
+            if (tracer == 6) return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 2>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
             return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
         }
     }

@@ -1007,6 +1007,40 @@ def test_state_once_kernel_with_sources_and_tracer_on_many_tiles(order, nx, ny, 
     assert relmax(out[False][2][1], hu) > 1e-6                    # the state moved
 
 
+@pytest.mark.parametrize("order,nx,ny", [(5, 31, 27), (6, 26, 33), (7, 23, 17), (8, 21, 25)])
+def test_variant_b_on_the_state_once_kernel_on_many_tiles(order, nx, ny, monkeypatch):
+    """Variant B's stage kernel on the state-once schedule (sw2d_mfma3src_kernel.hpp, PHYS = 2; the default at N >= 5; at
+    N = 8 without the next-tile prefetch) with several tiles per wave, a ragged last tile and a shuffled element order,
+    against the two-waves-per-SIMD kernel it replaces (BDG_SW2D_SOURCES_TWO_WAVE=1, itself checked against the oracle at
+    every order above): RHS, filtered RHS, LSERK4 stages and SSP-RK2 + sponge-field steps agree to round-off."""
+    from conftest import variant_b_setup
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(nx, ny, shuffleSeed=31)
+    out = {}
+    for two_wave in (True, False):
+        if two_wave:
+            monkeypatch.setenv("BDG_SW2D_SOURCES_TWO_WAVE", "1")
+        else:
+            monkeypatch.delenv("BDG_SW2D_SOURCES_TWO_WAVE")
+        nodes, t, e = variant_b_setup(order, mesh)
+        Hx, Hy = nodes.bedSlopes(e["H"])
+        s = _variant_b_solver(nodes, e, Hx, Hy, sponge=2e-3 * np.exp(-4 * (t["x"] + 1.0) ** 2))
+        res = [s.computeRHS(e["h"], e["hu"], e["hv"]), s.computeRHS(e["h"], e["hu"], e["hv"], filter=True)]
+        s.setState(e["h"], e["hu"], e["hv"])
+        dt = 0.1 * s.computeDt(0.5)[0]
+        s.lserk4Stages(dt, 7)
+        res.append(s.getState())
+        s.setState(e["h"], e["hu"], e["hv"])
+        s.time = e["time"]
+        s.stepSSPRK2(dt, 3, False, 0.0)
+        res.append(s.getState())
+        out[two_wave] = res
+    for a, b in zip(out[True], out[False]):
+        for u, v in zip(a, b):
+            assert relmax(v, u) < 1e-13
+    assert relmax(out[False][2][1], e["hu"]) > 1e-7               # the state moved
+
+
 @pytest.mark.parametrize("case", ["coarse_box_N4", "coarse_box_N6"])
 def test_tracer_in_its_own_pass_as_cross_check(case, monkeypatch):
     """By default the tracer equation rides in the three-field kernel as a fourth accumulator set (N <= 6);
