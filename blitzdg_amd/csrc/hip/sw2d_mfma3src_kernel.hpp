@@ -13,6 +13,9 @@
 // Same schedule as sw2d_stage_mfma3_kernel (one wave per SIMD, next tile requested piece by piece, update per 16-row
 // block); the source tables' rows of the NEXT tile are requested with its state rows. A table that is absent gets an empty
 // descriptor (its loads return 0) and the Coriolis constant is picked by a select: no branch in the tile loop.
+// N = 8 (three fields only: four fields' state tiles would not fit the LDS beside the operators): nothing of the next tile
+// is requested ahead -- it would not fit the registers, and a spilled register costs more than an exposed round trip.
+// PHYS = 2: the stage kernel of variant B (the reference's tidal driver), see the template's comment.
 #pragma once
 #include "sw2d_mfma3_kernel.hpp"
 
