@@ -252,7 +252,8 @@ def distributed_line(world, steps, warmup, wall, K, Np, counts, transport, mass_
 
 
 def cap_host_threads(world):
-    """Host-side setup uses OpenMP; with one process per GPU keep the total thread count sane."""
+    """Host-side setup runs its element loops on up to OMP_NUM_THREADS (or BDG_NUM_THREADS) workers; with one process
+    per GPU keep the total thread count sane."""
     cores = os.cpu_count() or 8
     os.environ.setdefault("OMP_NUM_THREADS", str(max(1, min(16, cores // max(world, 1)))))
 

@@ -2,9 +2,11 @@
 // validation, device layout, operator image in MFMA tile order, launches. Kernels: sw2d_curved_kernel.hpp.
 // Reference: swhelpers/rhs.py:6-176 (the RHS), sw2d_curved.py:246-277 (the time loop).
 #include "../host/capi_internal.hpp"
+#include "../host/parallel_for.hpp"
 #include "blitzdg/LSERK4.hpp"
 #include "sw2d_curved_kernel.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -200,14 +202,14 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         return static_cast<int>((16ll * fb * f2 + l2) * ld + k2);
     };
     if (!identityM) offM.assign(static_cast<size_t>(GR) * K, 0);
-#pragma omp parallel for schedule(static)
-    for (int k = 0; k < K; ++k)
+    blitzdg::detail::parallelFor(K, [&](int k) {
         for (int gI = 0; gI < NG3; ++gI) {
             const int f = gI / NG, l = gI % NG;
             const size_t at = static_cast<size_t>(16 * fb * f + l) * K + k;
             offP[at] = devOffset(d.gmapP[static_cast<size_t>(k) * NG3 + gI]);
             if (!identityM) offM[at] = devOffset(d.gmapM[static_cast<size_t>(k) * NG3 + gI]);
         }
+    });
     for (int i = 0; i < d.num_wall; ++i) {
         const int w = d.gmapW[i];
         if (w < 0 || w >= nG) throw arg_error("bdg_sw2d_curved_create: wall Gauss-node index out of range");
@@ -250,8 +252,7 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         std::vector<double> tmp(static_cast<size_t>(Ncub) * K);
         const double* geo[4] = {d.cubrx, d.cubry, d.cubsx, d.cubsy};
         for (int t = 0; t < 4; ++t) {
-#pragma omp parallel for schedule(static)
-            for (long long i = 0; i < static_cast<long long>(Ncub) * K; ++i) tmp[i] = d.cubW[i] * geo[t][i];
+            blitzdg::detail::parallelFor(static_cast<long long>(Ncub) * K, [&](long long i) { tmp[i] = d.cubW[i] * geo[t][i]; }, 1 << 16);
             s->uploadRows(tmp.data(), s->cubG.p + static_cast<size_t>(t) * CR * ld, Ncub);
         }
     }
@@ -278,19 +279,23 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         if (kref >= 0) {
             std::vector<double> wref(static_cast<size_t>(CR), 0.0), ca(static_cast<size_t>(4) * K, 0.0);
             for (int i = 0; i < Ncub; ++i) wref[i] = d.cubW[static_cast<size_t>(i) * K + kref];
-            int count = 0;
-#pragma omp parallel for schedule(static) reduction(+ : count)
-            for (int k = 0; k < K; ++k) {
-                if (slotOf[k] >= 0 || !constantMetric(k)) continue; // elements of curvedEls keep the general path
-                const double ratio = d.cubW[k] / wref[0];
-                bool ok = ratio > 0.0;
-                for (int i = 1; i < Ncub && ok; ++i)
-                    ok = std::fabs(d.cubW[static_cast<size_t>(i) * K + k] - ratio * wref[i]) <= 1e-10 * std::fabs(ratio * wref[i]);
-                if (!ok) continue;
-                flag[k] = 1;
-                for (int t = 0; t < 4; ++t) ca[static_cast<size_t>(t) * K + k] = ratio * geo[t][k];
-                ++count;
-            }
+            std::atomic<int> counted{0};
+            blitzdg::detail::parallelChunks(K, [&](int kBegin, int kEnd) {
+                int mine = 0;
+                for (int k = kBegin; k < kEnd; ++k) {
+                    if (slotOf[k] >= 0 || !constantMetric(k)) continue; // elements of curvedEls keep the general path
+                    const double ratio = d.cubW[k] / wref[0];
+                    bool ok = ratio > 0.0;
+                    for (int i = 1; i < Ncub && ok; ++i)
+                        ok = std::fabs(d.cubW[static_cast<size_t>(i) * K + k] - ratio * wref[i]) <= 1e-10 * std::fabs(ratio * wref[i]);
+                    if (!ok) continue;
+                    flag[k] = 1;
+                    for (int t = 0; t < 4; ++t) ca[static_cast<size_t>(t) * K + k] = ratio * geo[t][k];
+                    ++mine;
+                }
+                counted += mine;
+            });
+            const int count = counted;
             s->numAffine = count;
             if (count) {
                 for (long long k = K; k < ld; ++k) flag[k] = flag[K - 1]; // (padding lanes repeat the last element)

@@ -13,11 +13,13 @@
 // Elements may be renumbered internally (BDG_SW2D_REORDER); all I/O is in the
 // caller's numbering.
 #include "../host/capi_internal.hpp"
+#include "../host/parallel_for.hpp"
 #include "blitzdg/LSERK4.hpp"
 #include "sw2d_launch.hpp"
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -917,9 +919,8 @@ std::vector<int> bfsOrder(const int* vmapP, int K, int Np, int Nfp) {
 // real curvature.
 bool geometryIsAffine(const bdg_sw2d_desc& d, int Np, int Nfp, int K) {
     const double tol = 1e-8;
-    bool ok = true;
-#pragma omp parallel for schedule(static) reduction(&& : ok)
-    for (int k = 0; k < K; ++k) {
+    std::atomic<bool> ok{true};
+    blitzdg::detail::parallelFor(K, [&](int k) {
         const double scale = std::fabs(d.rx[k]) + std::fabs(d.sx[k]) + std::fabs(d.ry[k]) + std::fabs(d.sy[k]);
         for (int n = 1; n < Np; ++n) {
             const size_t o = static_cast<size_t>(n) * K + k;
@@ -936,7 +937,7 @@ bool geometryIsAffine(const bdg_sw2d_desc& d, int Np, int Nfp, int K) {
                     ok = false;
             }
         }
-    }
+    });
     return ok;
 }
 
@@ -1022,11 +1023,15 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     // 0.37 ms renumbered; natural order: 0.38 ms either way).
     bool reorder = (d.flags & BDG_SW2D_REORDER) != 0;
     if (!reorder && !(d.flags & BDG_SW2D_KEEP_ORDER)) {
-        double sum = 0.0;
-#pragma omp parallel for schedule(static) reduction(+ : sum)
-        for (int k = 0; k < K; ++k)
-            for (int f = 0; f < 3; ++f)
-                sum += std::fabs(static_cast<double>(d.vmapP[(static_cast<size_t>(k) * 3 + f) * Nfp] / Np - k));
+        std::atomic<long long> total{0};        // integers: the same sum whatever the number of workers
+        blitzdg::detail::parallelChunks(K, [&](int kBegin, int kEnd) {
+            long long mine = 0;
+            for (int k = kBegin; k < kEnd; ++k)
+                for (int f = 0; f < 3; ++f)
+                    mine += std::llabs(static_cast<long long>(d.vmapP[(static_cast<size_t>(k) * 3 + f) * Nfp] / Np) - k);
+            total += mine;
+        });
+        const double sum = static_cast<double>(total.load());
         reorder = sum / (3.0 * K) > 4.0 * std::sqrt(static_cast<double>(K));
     }
     if (reorder) s->permHost = bfsOrder(d.vmapP, K, Np, Nfp);

@@ -3,6 +3,7 @@
 // (blitzdg_amd/pyblitzdg.py) can mirror the reference's boost::python module
 // (src/pyblitzdg/pyblitzdg.cpp:59-201) without copying on this side.
 #include "capi_internal.hpp"
+#include "parallel_for.hpp"
 #include "blitzdg/Advec1d.hpp"
 #include "blitzdg/LSERK4.hpp"
 #include "blitzdg/VtkOutputter.hpp"
@@ -166,9 +167,9 @@ int bdg_trinodes_bed_slopes(const bdg_trinodes* nodes, const double* H, double* 
         const real_matrix_type& Dr = p.get_Dr(), &Ds = p.get_Ds(), &F = p.get_Filter();
         if (F.rows() != Np) throw bdg_detail::arg_error("bdg_trinodes_bed_slopes: call buildFilter first");
         const real_matrix_type& rx = p.get_rx(), &sx = p.get_sx(), &ry = p.get_ry(), &sy = p.get_sy();
-#pragma omp parallel for schedule(static)
-        for (int k = 0; k < K; ++k) {
-            std::vector<double> gx(Np), gy(Np);
+        blitzdg::detail::parallelChunks(K, [&](int kBegin, int kEnd) {
+        std::vector<double> gx(Np), gy(Np);
+        for (int k = kBegin; k < kEnd; ++k) {
             for (int i = 0; i < Np; ++i) {
                 double dr = 0.0, ds = 0.0;
                 for (int m = 0; m < Np; ++m) {
@@ -188,6 +189,7 @@ int bdg_trinodes_bed_slopes(const bdg_trinodes* nodes, const double* H, double* 
                 Hy[static_cast<size_t>(i) * K + k] = ay;
             }
         }
+        });
     });
 }
 
@@ -209,8 +211,7 @@ int bdg_trinodes_sponge_coeff(const bdg_trinodes* nodes, const int* mapO, int nu
             xo[i] = x(v % Np, v / Np);
             yo[i] = y(v % Np, v / Np);
         }
-#pragma omp parallel for schedule(static)
-        for (int k = 0; k < K; ++k)
+        blitzdg::detail::parallelFor(K, [&](int k) {
             for (int n = 0; n < Np; ++n) {
                 double closest = 1.0e12;
                 for (int i = 0; i < num_out; ++i) {
@@ -219,6 +220,7 @@ int bdg_trinodes_sponge_coeff(const bdg_trinodes* nodes, const int* mapO, int nu
                 }
                 coeff[static_cast<size_t>(n) * K + k] = closest < 1.0e12 ? strength * (1.0 - closest / radius) : 0.0;
             }
+        }, 16);
     });
 }
 

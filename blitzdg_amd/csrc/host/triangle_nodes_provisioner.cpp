@@ -1,4 +1,4 @@
-// TriangleNodesProvisioner implementation (setup path; CPU, OpenMP over elements).
+// TriangleNodesProvisioner implementation (setup path; CPU, element loops on std::thread workers).
 //
 // Restates the table construction of the reference's
 // src/TriangleNodesProvisioner.cpp with plain loops:
@@ -9,6 +9,7 @@
 // The index maps must come out bit-identical to the reference's (its tests pin
 // them on input/coarse_box.msh); real-valued tables agree to round-off.
 #include "blitzdg/TriangleNodesProvisioner.hpp"
+#include "parallel_for.hpp"
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -339,11 +340,9 @@ void TriangleNodesProvisioner::buildPhysicalGrid() {
     computeGradVandermondeMatrix(NOrder, rGrid, sGrid, V2Dr, V2Ds);
     computeDifferentiationMatrices(V2Dr, V2Ds, V, V, Dr, Ds, Drw, Dsw);
 
-#pragma omp parallel
-    {
+    detail::parallelChunks(K, [&](index_type kBegin, index_type kEnd) {
         std::vector<real_type> xr(Np), xs(Np), yr(Np), ys(Np), xe(Np), ye(Np);
-#pragma omp for schedule(static)
-        for (index_type k = 0; k < K; ++k) {
+        for (index_type k = kBegin; k < kEnd; ++k) {
             const index_type va = EToV(3 * k), vb = EToV(3 * k + 1), vc = EToV(3 * k + 2);
             const real_type xa = Vert(3 * va), xb = Vert(3 * vb), xc = Vert(3 * vc);
             const real_type ya = Vert(3 * va + 1), yb = Vert(3 * vb + 1), yc = Vert(3 * vc + 1);
@@ -385,7 +384,7 @@ void TriangleNodesProvisioner::buildPhysicalGrid() {
                     Fscale(row, k) = norm / J(v, k);
                 }
         }
-    }
+    });
 }
 
 void TriangleNodesProvisioner::setCoordinates(const real_type* x, const real_type* y) {
@@ -403,8 +402,7 @@ void TriangleNodesProvisioner::buildMaps() {
     const real_vector_type& Vert = Mesh2D->get_Vertices();
 
     // Volume node (n,k) has id n + Np*k. Flat face-node index: n + Nfp*f + 3*Nfp*k.
-#pragma omp parallel for schedule(static)
-    for (index_type k = 0; k < K; ++k)
+    detail::parallelFor(K, [&](index_type k) {
         for (index_type f = 0; f < NumFaces; ++f) {
             const index_type k2 = E2E(NumFaces * k + f), f2 = E2F(NumFaces * k + f);
             // Reference length of the edge: distance between its two vertices.
@@ -430,6 +428,7 @@ void TriangleNodesProvisioner::buildMaps() {
                 mapP(flat) = mP;
             }
         }
+    });
 
     // Boundary face nodes: vmapP == vmapM.
     const index_type total = K * NumFaces * Nfp;
@@ -548,15 +547,14 @@ void TriangleNodesProvisioner::splitElements(const real_matrix_type& x, const re
     const index_type nLocal = static_cast<index_type>(tri.size() / 3);
     auto interpolate = [&](const real_matrix_type& f) { // (Np, Np) x (Np, K), K contiguous
         real_matrix_type out(Np, K);
-#pragma omp parallel for schedule(static)
-        for (index_type i = 0; i < Np; ++i) {
+        detail::parallelFor(Np, [&](index_type i) {
             real_type* o = out.data() + static_cast<std::size_t>(i) * K;
             for (index_type m = 0; m < Np; ++m) {
                 const real_type a = IM(i, m);
                 const real_type* src = f.data() + static_cast<std::size_t>(m) * K;
                 for (index_type k = 0; k < K; ++k) o[k] += a * src[k];
             }
-        }
+        }, 1);
         return out;
     };
     const real_matrix_type rx_ = interpolate(x), ry_ = interpolate(y), rf = interpolate(field);

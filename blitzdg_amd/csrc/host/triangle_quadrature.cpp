@@ -3,12 +3,14 @@
 // plus the computed TriangleCubatureRules.
 //
 // Restates the reference's src/TriangleNodesProvisioner.cpp:207-381 (Gauss face nodes) and :81-205
-// (cubature volume mesh) with plain loops, element-parallel (OpenMP). The Gauss-node maps mapM / mapP
+// (cubature volume mesh) with plain loops, element-parallel (parallel_for.hpp). The Gauss-node maps mapM / mapP
 // and the BC lists must come out identical to the reference's construction (face-major BC order,
 // neighbour face traversed backwards); real tables agree to round-off. The cubature RULE is computed,
 // not tabulated (see include/blitzdg/TriangleCubatureRules.hpp).
 #include "blitzdg/TriangleCubatureRules.hpp"
 #include "blitzdg/TriangleNodesProvisioner.hpp"
+#include "parallel_for.hpp"
+#include <atomic>
 #include <cmath>
 #include <stdexcept>
 #include <vector>
@@ -85,8 +87,7 @@ GaussFaceContext2D TriangleNodesProvisioner::buildGaussFaceNodes(index_type NGau
     const index_vector_type& E2F = Mesh2D->get_EToF();
     const index_vector_type& bcVec = Mesh2D->get_BCType();
 
-#pragma omp parallel for schedule(static)
-    for (index_type k = 0; k < K; ++k) {
+    detail::parallelFor(K, [&](index_type k) {
         for (index_type f = 0; f < NF; ++f) {
             for (index_type ig = 0; ig < Ng; ++ig) {
                 real_type xr = 0, yr = 0, xs = 0, ys = 0, gx = 0, gy = 0;
@@ -116,7 +117,7 @@ GaussFaceContext2D TriangleNodesProvisioner::buildGaussFaceNodes(index_type NGau
                 t.mapP(row + k * Nfp) = (k != k2) ? (Ng * (f2 + 1) - ig - 1) + k2 * Nfp : row + k * Nfp;
             }
         }
-    }
+    });
     // boundary lists in the reference's order: faces outermost, then elements, then Gauss points (:253, :328-335)
     for (index_type tag : {3, 6, 7, 1, 2, 4, 5, 8}) t.bcMap[tag];   // Wall, Dirichlet, Neuman, In, Out, Cyl, Far, Slip
     for (index_type f = 0; f < NF; ++f)
@@ -152,14 +153,12 @@ CubatureContext2D TriangleNodesProvisioner::buildCubatureVolumeMesh(index_type N
     t.MM = real_tensor3_type(Np, Np, K);
     t.MMChol = real_tensor3_type(Np, Np, K);
 
-    bool notPositive = false;
-#pragma omp parallel
-    {
+    std::atomic<bool> notPositive{false};
+    detail::parallelChunks(K, [&](index_type kBegin, index_type kEnd) {
         std::vector<real_type> xe(Np), ye(Np), jw(Ncub);
         real_matrix_type MMk(Np, Np), R(Np, Np);
         DenseCholeskyFactorizer chol;
-#pragma omp for schedule(static)
-        for (index_type k = 0; k < K; ++k) {
+        for (index_type k = kBegin; k < kEnd; ++k) {
             for (index_type m = 0; m < Np; ++m) { xe[m] = xGrid(m, k); ye[m] = yGrid(m, k); }
             for (index_type i = 0; i < Ncub; ++i) {
                 real_type xr = 0, xs = 0, yr = 0, ys = 0, xc = 0, yc = 0;
@@ -196,7 +195,6 @@ CubatureContext2D TriangleNodesProvisioner::buildCubatureVolumeMesh(index_type N
             try {
                 chol.computeCholesky(MMk, R);
             } catch (const std::runtime_error&) {
-#pragma omp atomic write
                 notPositive = true;
                 continue;
             }
@@ -206,7 +204,7 @@ CubatureContext2D TriangleNodesProvisioner::buildCubatureVolumeMesh(index_type N
                     t.MMChol(i, j, k) = R(i, j);
                 }
         }
-    }
+    }, 16);
     if (notPositive)
         throw std::runtime_error("buildCubatureVolumeMesh: an element's cubature mass matrix is not positive definite "
                                  "(inverted element?)");

@@ -15,6 +15,106 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---- child processes: never forked from this (soon GPU-initialised) process, but by tests/launcher.py, which is
+# ---- started here, at session start, before any test has loaded the HIP library
+
+_launcher = None
+
+
+def _hip_is_mapped():
+    try:
+        with open("/proc/self/maps") as f:
+            return any("libamdhip64" in ln or "libhsa-runtime64" in ln for ln in f)
+    except OSError:
+        return False
+
+
+def _start_launcher():
+    global _launcher
+    if _launcher is not None and _launcher.poll() is None:
+        return _launcher
+    assert not _hip_is_mapped(), "tests/launcher.py must be started before this process loads the HIP runtime"
+    import subprocess
+    _launcher = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "launcher.py")], stdin=subprocess.PIPE,
+                                 stdout=subprocess.PIPE, text=True, bufsize=1)
+    return _launcher
+
+
+def pytest_sessionstart(session):
+    _start_launcher()
+
+
+def pytest_sessionfinish(session, exitstatus):
+    global _launcher
+    if _launcher is not None:
+        try:
+            _launcher.stdin.close()         # EOF ends its loop
+            _launcher.wait(timeout=30)
+        except Exception:
+            _launcher.kill()
+        _launcher = None
+
+
+class Completed:
+    """What subprocess.run(capture_output=True, text=True) returns, for a command tests/launcher.py ran."""
+
+    def __init__(self, argv, returncode, stdout, stderr):
+        self.args, self.returncode, self.stdout, self.stderr = argv, returncode, stdout, stderr
+
+
+def launch_group(cmds, timeout=600):
+    """Run commands side by side through the launcher; cmds = [(argv, env or None, cwd or None), ...]."""
+    import json
+    proc = _start_launcher()
+    req = {"cmds": [{"argv": [str(a) for a in argv], "env": env, "cwd": cwd} for argv, env, cwd in cmds], "timeout": timeout}
+    proc.stdin.write(json.dumps(req) + "\n")
+    proc.stdin.flush()
+    line = proc.stdout.readline()
+    assert line, "tests/launcher.py went away"
+    reply = json.loads(line)
+    assert "error" not in reply, reply.get("error")
+    return [Completed(c[0], r["returncode"], r["stdout"], r["stderr"]) for c, r in zip(cmds, reply["results"])]
+
+
+def launch(argv, env=None, cwd=None, timeout=600):
+    """subprocess.run(argv, capture_output=True, text=True, ...) without a fork of this process."""
+    return launch_group([(argv, env, cwd)], timeout)[0]
+
+
+def launch_ranks(module, function, nprocs, args, env=None, timeout=900):
+    """function(rank, *args) of tests/<module>.py in `nprocs` fresh interpreters, side by side (what
+    torch.multiprocessing.start_processes(..., start_method="spawn", join=True) did from inside this process).
+    args must survive JSON. Fails the test with the workers' output when one of them fails."""
+    import json
+    worker = os.path.join(ROOT, "tests", "rank_worker.py")
+    env = dict(os.environ if env is None else env)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    done = launch_group([([sys.executable, worker, module, function, str(r), json.dumps(list(args))], env, ROOT)
+                         for r in range(nprocs)], timeout)
+    bad = [(r, d) for r, d in enumerate(done) if d.returncode != 0]
+    assert not bad, "".join(f"\n--- rank {r} exit {d.returncode}\n{d.stdout[-1500:]}{d.stderr[-3000:]}" for r, d in bad)
+    return done
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_fork_nothing_and_keep_torch_out(request, monkeypatch):
+    """A GPU test runs in a process that holds the HIP runtime: it may neither fork (subprocess / multiprocessing go
+    through launch() / launch_ranks() above) nor pull PyTorch -- a second copy of the ROCm runtime libraries and an
+    OpenMP runtime -- into this process."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import subprocess
+
+    def refuse(*a, **k):
+        raise AssertionError("a GPU test must not fork the pytest process: use conftest.launch / launch_ranks")
+    had_torch = "torch" in sys.modules
+    monkeypatch.setattr(subprocess, "Popen", refuse)
+    monkeypatch.setattr(os, "fork", refuse)
+    yield
+    assert had_torch or "torch" not in sys.modules, "a GPU test imported torch into the pytest process"
+
+
 @pytest.fixture(scope="session")
 def known():
     """Known-answer vectors parsed from the reference's unit tests (tests/golden/make_golden.py)."""

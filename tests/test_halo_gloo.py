@@ -6,7 +6,8 @@ its partition-boundary elements, exchanges them with torch.distributed (the same
 exchange_ops the GPU path hands to RCCL), unpacks into the ghost slots and advances. The
 owned results must equal a single-domain run BIT FOR BIT (per-element arithmetic does not
 depend on the numbering), which pins the partition, the local renumbering, the ghost ordering
-on both sides and the wall flags of the local meshes.
+on both sides and the wall flags of the local meshes. The rank processes are started by tests/launcher.py
+(conftest.launch_ranks): PyTorch lives in the workers only, never in the pytest process.
 """
 import os
 import socket
@@ -88,15 +89,13 @@ def _worker(rank, world, port, mesh_args, order, nstages, out_dir):
 
 @pytest.mark.parametrize("world,mesh_args,order", [(2, (6, 4, 0), 3), (2, (5, 7, 12345), 2), (3, (8, 6, 77), 4)])
 def test_partitioned_lserk4_equals_single_domain(tmp_path, world, mesh_args, order):
-    import torch.multiprocessing as mp
-
     import blitzdg_amd.pyblitzdg as dg
+    from conftest import launch_ranks
     from oracle import Sw2dOracle
 
     nstages = 7
     port = _free_port()
-    mp.start_processes(_worker, args=(world, port, mesh_args, order, nstages, str(tmp_path)), nprocs=world,
-                       join=True, start_method="spawn")
+    launch_ranks("test_halo_gloo", "_worker", world, (world, port, mesh_args, order, nstages, str(tmp_path)))
 
     mesh = dg.MeshManager()
     mesh.buildBoxMesh(*mesh_args[:2], shuffleSeed=mesh_args[2])
@@ -207,14 +206,12 @@ def _b_worker(rank, world, port, mesh_args, order, nsteps, dt, out_dir):
 def test_partitioned_variant_b_with_all_reduced_speed_equals_single_domain(tmp_path, world, mesh_args, order):
     """Variant B's ONE global speed (reference src/sw2d/main.cpp:414) in a partitioned run = max over ranks of the
     owned-element maxima: Heun steps on 2 and 3 ranks equal the single-domain restatement bit for bit."""
-    import torch.multiprocessing as mp
-
     import blitzdg_amd.pyblitzdg as dg
+    from conftest import launch_ranks
     from oracle import oracle_np as onp
 
     nsteps, dt = 3, 1e-3
-    mp.start_processes(_b_worker, args=(world, _free_port(), mesh_args, order, nsteps, dt, str(tmp_path)), nprocs=world,
-                       join=True, start_method="spawn")
+    launch_ranks("test_halo_gloo", "_b_worker", world, (world, _free_port(), mesh_args, order, nsteps, dt, str(tmp_path)))
     mesh = dg.MeshManager()
     mesh.buildBoxMesh(*mesh_args[:2], shuffleSeed=mesh_args[2])
     _open_left_edge(mesh)

@@ -352,7 +352,7 @@ def test_host_setup_code_is_clean_under_address_and_ub_sanitizers(tmp_path):
     srcs = [f for f in glob.glob(os.path.join(root, "blitzdg_amd", "csrc", "host", "*.cpp"))
             if os.path.basename(f) not in ("capi_host.cpp", "sw2d_frontend.cpp")]
     exe = str(tmp_path / "host_check")
-    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fopenmp",
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-pthread",
            "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "blitzdg_amd", "csrc", "host"),
            os.path.join(root, "tests", "host_sanitizer_check.cpp"), *srcs, "-o", exe]
     build = subprocess.run(cmd, capture_output=True, text=True, timeout=600)

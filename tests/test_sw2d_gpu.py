@@ -18,7 +18,7 @@ import pytest
 import blitzdg_amd.pyblitzdg as dg
 from blitzdg_amd import sw2d
 from blitzdg_amd._capi import BdgError, NumericalInstability
-from conftest import load_case, oracle_from, relmax, seeded_fields, tables_from_nodes
+from conftest import launch, load_case, oracle_from, relmax, seeded_fields, tables_from_nodes
 
 pytestmark = pytest.mark.gpu
 
@@ -312,12 +312,10 @@ def test_cpp_driver_sw2d_simple_matches_oracle_replay(coarse_mesh):
     coarse_box at N=3 must land on the same t and momentum as the oracle replay."""
     import os
     import re
-    import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "bin", "sw2d-simple")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), "3", "1e9", "25"],
-                         capture_output=True, text=True, timeout=300)
+    out = launch([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), "3", "1e9", "25"], timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"done: steps=(\d+), t=([-+.\deE]+), eta_max=([-+.\deE]+), \|hu\|max=([-+.\deE]+)", out.stdout)
     assert m, out.stdout
@@ -338,8 +336,7 @@ def test_cpp_driver_sw2d_simple_matches_oracle_replay(coarse_mesh):
     # with an output directory the driver also writes eta/u/v *.vtu every 10 steps (reference :123-131)
     outdir = os.path.join(root, "gpurun_out", "vtu_test")
     os.makedirs(outdir, exist_ok=True)
-    out2 = subprocess.run([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), "3", "1e9", "25", outdir],
-                          capture_output=True, text=True, timeout=300)
+    out2 = launch([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), "3", "1e9", "25", outdir], timeout=300)
     assert out2.returncode == 0, out2.stdout + out2.stderr
     assert sorted(os.listdir(outdir)) == sorted(f"{n}{c:07d}.vtu" for n in ("eta", "u", "v") for c in (0, 10, 20))
     assert b"UnstructuredGrid" in open(os.path.join(outdir, "eta0000020.vtu"), "rb").read(300)
@@ -615,15 +612,13 @@ def test_cpp_driver_sw2d_tidal_matches_oracle_replay(mode, coarse_mesh):
     sw2d::computeRHS(fields, num, phys, dg, t) must land on the oracle replay's state after 12 steps."""
     import os
     import re
-    import subprocess
     from conftest import variant_b_setup
     from oracle import oracle_np as onp
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "bin", "sw2d")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
     order, steps = 2, 12
-    out = subprocess.run([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), str(order), str(steps), mode],
-                         capture_output=True, text=True, timeout=300)
+    out = launch([exe, os.path.join(root, "tests", "golden", "coarse_box.msh"), str(order), str(steps), mode], timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     m = re.search(r"done: mode=(\w+), steps=(\d+), t=([-+.\deE]+), eta_max=([-+.\deE]+), \|hu\|max=([-+.\deE]+), "
                   r"\|hv\|max=([-+.\deE]+)", out.stdout)
@@ -937,10 +932,9 @@ def test_smallest_mesh_two_triangles(order):
 def test_cpp_drivers_accept_a_synthetic_box_argument():
     """`box:NXxNY` instead of a mesh file (the 'x' of 'box' must not be taken for the separator)."""
     import os
-    import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for exe, args in (("sw2d-simple", ["box:12x7", "2", "1e9", "5"]), ("sw2d", ["box:12x7", "2", "5", "resident"])):
-        out = subprocess.run([os.path.join(root, "bin", exe), *args], capture_output=True, text=True, timeout=300)
+        out = launch([os.path.join(root, "bin", exe), *args], timeout=300)
         assert out.returncode == 0 and "steps=5" in out.stdout, out.stdout + out.stderr
 
 
