@@ -48,15 +48,29 @@ def actual_bytes_per_element(order, affine):
     return 3 * np_ * 8 * 4 + geo + 3 * nfp * 4
 
 
+_COMMENT_OR_STRING = None
+
+
+def strip_comments(text):
+    """C++ source without comments and with runs of white space collapsed (string literals kept as they are)."""
+    import re
+    global _COMMENT_OR_STRING
+    if _COMMENT_OR_STRING is None:
+        _COMMENT_OR_STRING = re.compile(r'//[^\n]*|/\*.*?\*/|"(?:\\.|[^"\\\n])*"|\'(?:\\.|[^\'\\\n])*\'', re.S)
+    code = _COMMENT_OR_STRING.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", text)
+    return " ".join(code.split())
+
+
 def kernel_source_sha():
-    """Hash of the device sources: a committed PMC summary is only quoted while it still describes
-    the kernels that are being timed (profiles/summarize.py records the same hash)."""
+    """Hash of the device sources WITHOUT their comments and layout: a committed PMC summary is only quoted while it
+    still describes the kernels that are being timed (profiles/summarize.py records the same hash), and a comment or
+    re-indentation does not invalidate a collection (in round 2 a header comment cost a full PMC run)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "blitzdg_amd", "csrc", "hip", "*"))):
         h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+        h.update(strip_comments(open(f, errors="replace").read()).encode())
     return h.hexdigest()[:16]
 
 
@@ -231,7 +245,7 @@ def distributed_line(world, steps, warmup, wall, K, Np, counts, transport, mass_
     bytes_elem = algorithmic_bytes_per_element(ORDER)
     achieved = bytes_elem * K * steps / wall / 1e9
     return {
-        "metric": "element-DOF updates/sec (sw2d RHS + LSERK4 stage, N=4, 1M tris)",
+        "metric": f"element-DOF updates/sec (sw2d RHS + LSERK4 stage, N={ORDER}, {K / 1e6:g}M tris)",
         "value": Np * K * steps / wall,
         "unit": "element-DOF updates/s",
         "n_gpus": world, "steps": steps, "warmup": warmup,

@@ -127,6 +127,8 @@ _SIGNATURES = {
     "bdg_gaussctx_bcmap_tags": (c_int, [_P, POINTER(c_int), c_int]),
     "bdg_gaussctx_bcmap_nodes": (c_int, [_P, c_int, POINTER(POINTER(c_int)), POINTER(c_int)]),
     "bdg_trinodes_build_cubature_volume_mesh": (c_int, [_P, c_int, POINTER(_P)]),
+    "bdg_cubature_rule_num_points": (c_int, [c_int]),
+    "bdg_cubature_rule": (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "bdg_cubctx_destroy": (None, [_P]),
     "bdg_cubctx_num_points": (c_int, [_P]),
     "bdg_cubctx_order": (c_int, [_P]),

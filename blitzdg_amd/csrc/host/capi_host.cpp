@@ -6,6 +6,7 @@
 #include "parallel_for.hpp"
 #include "blitzdg/Advec1d.hpp"
 #include "blitzdg/LSERK4.hpp"
+#include "blitzdg/TriangleCubatureRules.hpp"
 #include "blitzdg/VtkOutputter.hpp"
 #include <algorithm>
 #include <cmath>
@@ -431,6 +432,21 @@ int bdg_trinodes_build_cubature_volume_mesh(bdg_trinodes* nodes, int NCubature, 
         if (!nodes || !out) throw bdg_detail::arg_error("bdg_trinodes_build_cubature_volume_mesh: NULL argument");
         if (NCubature < 1) throw bdg_detail::arg_error("bdg_trinodes_build_cubature_volume_mesh: NCubature must be >= 1");
         *out = new bdg_cubctx{nodes->prov.buildCubatureVolumeMesh(NCubature)};
+    });
+}
+
+int bdg_cubature_rule_num_points(int NCubature) {
+    int n = -1;
+    guard([&] { n = TriangleCubatureRules(NCubature).NumCubaturePoints(); });
+    return n;
+}
+
+int bdg_cubature_rule(int NCubature, double* r, double* s, double* w) {
+    return guard([&] {
+        if (!r || !s || !w) throw bdg_detail::arg_error("bdg_cubature_rule: NULL argument");
+        const TriangleCubatureRules rule(NCubature);
+        const real_vector_type rr = rule.rCoord(), ss = rule.sCoord(), ww = rule.weights();
+        for (index_type i = 0; i < rule.NumCubaturePoints(); ++i) { r[i] = rr(i); s[i] = ss(i); w[i] = ww(i); }
     });
 }
 

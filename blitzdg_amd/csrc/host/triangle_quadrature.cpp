@@ -1,12 +1,11 @@
 // Face-quadrature and volume-cubature meshes of the triangle provisioner (curved / over-integrated
 // right-hand sides): TriangleNodesProvisioner::buildGaussFaceNodes and ::buildCubatureVolumeMesh,
-// plus the computed TriangleCubatureRules.
+// plus TriangleCubatureRules (the reference's tabulated rules; a computed rule beyond its table).
 //
 // Restates the reference's src/TriangleNodesProvisioner.cpp:207-381 (Gauss face nodes) and :81-205
 // (cubature volume mesh) with plain loops, element-parallel (parallel_for.hpp). The Gauss-node maps mapM / mapP
 // and the BC lists must come out identical to the reference's construction (face-major BC order,
-// neighbour face traversed backwards); real tables agree to round-off. The cubature RULE is computed,
-// not tabulated (see include/blitzdg/TriangleCubatureRules.hpp).
+// neighbour face traversed backwards); real tables agree to round-off.
 #include "blitzdg/TriangleCubatureRules.hpp"
 #include "blitzdg/TriangleNodesProvisioner.hpp"
 #include "parallel_for.hpp"
@@ -17,21 +16,44 @@
 
 namespace blitzdg {
 
+namespace {
+#include "triangle_cubature_table.inc"
+} // namespace
+
 TriangleCubatureRules::TriangleCubatureRules(index_type NCubature) : NCubature_{NCubature} {
     if (NCubature < 1) throw std::runtime_error("TriangleCubatureRules: degree must be >= 1");
+    if (NCubature > NumPreComputed) {
+        *this = conical(NCubature);
+        return;
+    }
+    const index_type n = kCubatureCount[NCubature - 1];
+    const double* p = kCubaturePoints + 3 * static_cast<std::size_t>(kCubatureFirst[NCubature - 1]);
+    r_.resize(n); s_.resize(n); w_.resize(n);
+    for (index_type c = 0; c < n; ++c) {
+        r_(c) = p[3 * c];
+        s_(c) = p[3 * c + 1];
+        w_(c) = p[3 * c + 2];
+    }
+}
+
+TriangleCubatureRules TriangleCubatureRules::conical(index_type NCubature) {
+    if (NCubature < 1) throw std::runtime_error("TriangleCubatureRules: degree must be >= 1");
+    TriangleCubatureRules rule;
+    rule.NCubature_ = NCubature;
     const index_type n = (NCubature + 2) / 2; // 2n - 1 >= NCubature
     JacobiBuilders jac;
     real_vector_type a(n), wa(n), b(n), wb(n);
     jac.computeJacobiQuadWeights(0.0, 0.0, n - 1, a, wa); // Legendre
     jac.computeJacobiQuadWeights(1.0, 0.0, n - 1, b, wb); // weight (1 - b): the collapse Jacobian
-    r_.resize(n * n); s_.resize(n * n); w_.resize(n * n);
+    rule.r_.resize(n * n); rule.s_.resize(n * n); rule.w_.resize(n * n);
     index_type c = 0;
     for (index_type j = 0; j < n; ++j)       // b outer: points come out row by row in s
         for (index_type i = 0; i < n; ++i, ++c) {
-            r_(c) = 0.5 * (1.0 + a(i)) * (1.0 - b(j)) - 1.0;
-            s_(c) = b(j);
-            w_(c) = 0.5 * wa(i) * wb(j);      // dr ds = (1 - b)/2 da db
+            rule.r_(c) = 0.5 * (1.0 + a(i)) * (1.0 - b(j)) - 1.0;
+            rule.s_(c) = b(j);
+            rule.w_(c) = 0.5 * wa(i) * wb(j);      // dr ds = (1 - b)/2 da db
         }
+    return rule;
 }
 
 namespace {

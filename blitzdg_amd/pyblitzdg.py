@@ -11,7 +11,7 @@ over-integrated RHS's tables) come from ``buildGaussFaceNodes`` / ``buildCubatur
 import numpy as np
 
 from . import _capi as C
-from ._capi import byref, c_double, c_int, c_void_p, check, lib
+from ._capi import POINTER, byref, c_double, c_int, c_void_p, check, lib
 
 
 class _BCType:
@@ -38,6 +38,35 @@ class _LSERK4:
 
 
 LSERK4 = _LSERK4()
+
+
+class TriangleCubatureRules:
+    """reference: include/TriangleCubatureRules.hpp:11-1830 (a C++-only class there): the tabulated symmetric rule of
+    degree NCubature = 1..28 on the reference triangle; a computed conical-product rule beyond the table."""
+
+    def __init__(self, NCubature):
+        n = lib.bdg_cubature_rule_num_points(int(NCubature))
+        if n < 0:
+            raise ValueError("TriangleCubatureRules: degree must be >= 1")
+        self._NCubature = int(NCubature)
+        self._r, self._s, self._w = (np.empty(n, dtype=np.float64) for _ in range(3))
+        as_p = lambda a: a.ctypes.data_as(POINTER(c_double))
+        check(lib.bdg_cubature_rule(self._NCubature, as_p(self._r), as_p(self._s), as_p(self._w)))
+
+    def NCubature(self):
+        return self._NCubature
+
+    def NumCubaturePoints(self):
+        return self._r.size
+
+    def rCoord(self):
+        return self._r.copy()
+
+    def sCoord(self):
+        return self._s.copy()
+
+    def weights(self):
+        return self._w.copy()
 
 
 class MeshManager:

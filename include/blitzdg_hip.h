@@ -134,8 +134,9 @@ int bdg_trinodes_write_vtu(const bdg_trinodes* nodes, const char* path, const do
  * Gauss tables are (3*NGauss, K), Interp (3*NGauss, Np), mapM/mapP (3*NGauss*K) flat ids g + 3*NGauss*k.
  * Cubature tables are (Ncub, K), V/Dr/Ds (Ncub, Np), r/s/w (Ncub); MM and MMChol are the reference's
  * (Np, Np, K) tensors viewed as (Np*Np, K). build_cubature_volume_mesh also recomputes the provisioner's
- * nodal J, rx, ry, sx, sy from its current coordinates, as the reference does. The cubature rule is a
- * computed conical-product rule of the requested degree (include/blitzdg/TriangleCubatureRules.hpp). */
+ * nodal J, rx, ry, sx, sy from its current coordinates, as the reference does. The cubature rule is the
+ * reference's tabulated symmetric rule for degrees 1..28 (36 points at degree 12) and a computed conical-product
+ * rule beyond its table (include/blitzdg/TriangleCubatureRules.hpp). */
 enum {
     BDG_GAUSS_NX = 0, BDG_GAUSS_NY, BDG_GAUSS_SJ, BDG_GAUSS_J, BDG_GAUSS_RX, BDG_GAUSS_RY, BDG_GAUSS_SX,
     BDG_GAUSS_SY, BDG_GAUSS_X, BDG_GAUSS_Y, BDG_GAUSS_W, BDG_GAUSS_INTERP, BDG_GAUSS_MAPM, BDG_GAUSS_MAPP
@@ -156,6 +157,10 @@ void bdg_cubctx_destroy(bdg_cubctx* ctx);
 int bdg_cubctx_num_points(const bdg_cubctx* ctx);
 int bdg_cubctx_order(const bdg_cubctx* ctx);
 int bdg_cubctx_table(const bdg_cubctx* ctx, int which, bdg_table* out);
+/* TriangleCubatureRules (reference include/TriangleCubatureRules.hpp:1807-1830): number of points of the rule of
+ * degree NCubature (-1: bad degree), and its rCoord / sCoord / weights copied into caller arrays of that length. */
+int bdg_cubature_rule_num_points(int NCubature);
+int bdg_cubature_rule(int NCubature, double* r, double* s, double* w);
 
 /* ---------------------------------------------------------------- Nodes1DProvisioner
  * reference: include/Nodes1DProvisioner.hpp:25-302 */

@@ -30,6 +30,10 @@ Writes
   sw2d_rhsB_degenerate_<case>.npz
                             the same function on a state (uniform depth and speed, flat bed, Coriolis only)
                             for which the C++ driver's variant B must give the same RHS
+  sw2d_rhsB_bed_<case>.npz, sw2d_rhsB_bed_drag_<case>.npz
+                            the same function over a continuous, non-flat bed (zx = -Hx, zy = -Hy) on a state with
+                            v = 0 and |u| + sqrt(g h) uniform, without and with drag: variant B's star states,
+                            bed-slope source and RHS2 drag must reproduce it
   advec1d_rhs_N4_K100.npz   advec1dComputeRHS(u, c, nodes1d) of the reference SCRIPT advec1d.py:12-39
   sw2d_rhsC_<case>.npz      sw2dComputeRHS(h,hu,hv,hN,g,H,f,ctx) of the reference SCRIPT sw2d.py:37-146
                             ("variant C"), its two function definitions compiled on their own
@@ -196,6 +200,46 @@ def rhsB_degenerate_case(name, mesh, order, g=9.81, f=0.05):
     np.savez_compressed(os.path.join(HERE, f"sw2d_rhsB_degenerate_{name}.npz"), order=order, g=g, f=f, h=h, hu=hu, hv=hv,
                         H=h.copy(), rhs1=r[0], rhs2=r[1], rhs3=r[2], **tabs)
     print(f"sw2d_rhsB_degenerate_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} |rhs|max="
+          f"{max(abs(a).max() for a in r[:3]):.6g}")
+
+
+def rhsB_bed_case(name, mesh, order, CD, g=9.81, f=0.05):
+    """More of variant B (src/sw2d/main.cpp:279-484) pinned by the reference's Python RHS: a CONTINUOUS, NON-FLAT bed
+    H(x, y) -- the star states (:356-368) are exercised and must come out as the identity, the bed-slope source
+    (:461-469, RHS2 += g h Hx) is active and equals variant D's with zx = -Hx, zy = -Hy -- with v = 0 and
+    u = c0 - sqrt(g h), so that |u| + sqrt(g h) = c0 at every face node and B's one global speed (:414) equals every
+    face's own maximum. With CD > 0 the drag of RHS2 (:474, -CD u |u|) is pinned as well; v = 0 makes the drag of RHS3,
+    whose sign differs between the two sources (swhelpers/rhs.py:307), vanish in both. Coriolis on, walls everywhere.
+    Output of swhelpers.rhs.sw2dComputeRHS with hN = 0."""
+    import blitzdg_amd.pyblitzdg as dg
+    sys.path.insert(0, REF)
+    if not hasattr(np, "float"):
+        np.float = float
+    from swhelpers.rhs import sw2dComputeRHS
+
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    ctx = nodes.dgContext()
+    tabs = {k: getattr(ctx, k) for k in
+            ("Dr", "Ds", "Lift", "rx", "sx", "ry", "sy", "nx", "ny", "Fscale", "vmapM", "vmapP", "x", "y")}
+    tabs["Filter"] = ctx.filter
+    bcmap = ctx.BCmap
+    tabs["mapW"] = np.array(bcmap.get(3, []), dtype=np.int32)
+    x, y = tabs["x"], tabs["y"]
+    H = 10.0 + 1.5 * x - 0.8 * y * y + 0.3 * np.sin(3 * x) * np.cos(2 * y)
+    Hx, Hy = nodes.bedSlopes(H)                      # the driver's filtered gradient (src/sw2d/main.cpp:128-133)
+    h = H + 0.3 * np.exp(-4 * (x - 0.2) ** 2 - 4 * (y + 0.1) ** 2)
+    c0 = 1.25 * np.sqrt(g * h.max())
+    hu, hv = h * (c0 - np.sqrt(g * h)), np.zeros_like(h)
+    ref_ctx = types.SimpleNamespace(BCmap=bcmap, nx=tabs["nx"], ny=tabs["ny"], rx=tabs["rx"], sx=tabs["sx"],
+                                    ry=tabs["ry"], sy=tabs["sy"], Dr=tabs["Dr"], Ds=tabs["Ds"],
+                                    numFacePoints=ctx.numFacePoints, numElements=ctx.numElements,
+                                    numFaces=ctx.numFaces, Lift=tabs["Lift"], Fscale=tabs["Fscale"])
+    r = sw2dComputeRHS(h, hu, hv, np.zeros_like(h), -Hx, -Hy, g, H, f, CD, ref_ctx, tabs["vmapM"], tabs["vmapP"])
+    tag = "bed_drag" if CD else "bed"
+    np.savez_compressed(os.path.join(HERE, f"sw2d_rhsB_{tag}_{name}.npz"), order=order, g=g, f=f, CD=CD, c0=c0, h=h, hu=hu,
+                        hv=hv, H=H, Hx=Hx, Hy=Hy, rhs1=r[0], rhs2=r[1], rhs3=r[2], **tabs)
+    print(f"sw2d_rhsB_{tag}_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} c0={c0:.6g} |rhs|max="
           f"{max(abs(a).max() for a in r[:3]):.6g}")
 
 
@@ -377,6 +421,12 @@ def degenerate_b_cases():
     shuffled.buildBoxMesh(6, 5, shuffleSeed=12345)
     rhsB_degenerate_case("coarse_box_N3", coarse, 3)
     rhsB_degenerate_case("box6x5_shuffled_N6", shuffled, 6)
+    box = dg.MeshManager()
+    box.buildBoxMesh(3, 2)
+    for CD in (0.0, 2.5e-2):
+        rhsB_bed_case("coarse_box_N3", coarse, 3, CD)
+        rhsB_bed_case("box6x5_shuffled_N6", shuffled, 6, CD)
+        rhsB_bed_case("box3x2_N8", box, 8, CD)
 
 
 def curved_cases():
@@ -400,6 +450,8 @@ def curved_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "curved":
         curved_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "variant_b":
+        degenerate_b_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "degenerate_b":
         degenerate_b_cases()
     else:

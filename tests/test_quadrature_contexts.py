@@ -38,9 +38,7 @@ def test_cubature_volume_mesh(coarse_mesh, known):  # Should_Build_Cubature_Volu
     nodes = dg.TriangleNodesProvisioner(N, coarse_mesh)
     c = nodes.buildCubatureVolumeMesh(3 * (N + 1))
     Ncub = c.NumCubaturePoints
-    # the reference's TABULATED degree-12 rule has 36 points; the rule here is computed (conical product of
-    # Gauss-Legendre x Gauss-Jacobi(1,0), 7 x 7 at degree 12): the count differs, every exactness property holds
-    assert Ncub == 49 and c.NCubature == 12
+    assert Ncub == 36 and c.NCubature == 12                   # the reference's tabulated degree-12 rule (:504)
     fieldcub = c.V @ np.ones(10)
     assert abs(fieldcub.sum() - Ncub) < 1e-11                 # interpolation reproduces constants
     assert abs((fieldcub * c.w).sum() - 2.0) < EPS * 10       # area of the reference triangle
@@ -49,21 +47,48 @@ def test_cubature_volume_mesh(coarse_mesh, known):  # Should_Build_Cubature_Volu
     assert np.allclose(U.T @ U, c.MM[:, :, 7], rtol=0, atol=1e-15) and np.all(np.tril(U, -1) == 0)
 
 
-@pytest.mark.parametrize("degree", [2, 3, 5, 9, 12, 15, 20, 27])
-def test_computed_cubature_rule_is_exact_to_its_degree(coarse_mesh, degree):
+REFERENCE_RULE_SIZES = [1, 3, 6, 6, 7, 12, 15, 16, 19, 25, 28, 36, 40, 46, 54, 58, 66, 73, 82, 85, 93, 100, 106, 118, 126, 138, 145, 225]
+
+
+def _monomial_errors(c, degree):
     """Integrals of r^a s^b over the reference triangle {r, s >= -1, r + s <= 0} in closed form
     (shift to the unit simplex: int x^a y^b = a! b! / (a + b + 2)!, x = (r+1)/2, scale 4)."""
     from math import factorial
-    nodes = dg.TriangleNodesProvisioner(1, coarse_mesh)
-    c = nodes.buildCubatureVolumeMesh(degree)
-    r, s, w = c.r, c.s, c.w
-    assert np.all(w > 0) and np.all(r > -1) and np.all(s > -1) and np.all(r + s < 0)
-    x, y = (r + 1) / 2, (s + 1) / 2
+    x, y, worst = (c.r + 1) / 2, (c.s + 1) / 2, 0.0
     for a in range(degree + 1):
         for b in range(degree + 1 - a):
             exact = 4.0 * factorial(a) * factorial(b) / factorial(a + b + 2)
-            assert abs((w * x ** a * y ** b).sum() - exact) < 2e-14
+            worst = max(worst, abs((c.w * x ** a * y ** b).sum() - exact))
+    return worst
+
+
+class _Rule:
+    def __init__(self, degree):
+        rule = dg.TriangleCubatureRules(degree)
+        self.r, self.s, self.w, self.n = rule.rCoord(), rule.sCoord(), rule.weights(), rule.NumCubaturePoints()
+
+
+@pytest.mark.parametrize("degree", range(1, 29))
+def test_tabulated_cubature_rules_have_the_reference_sizes_and_are_exact_to_their_degree(degree):
+    """Degrees 1..28: the reference's table (include/TriangleCubatureRules.hpp:26-1804), rule NCubature-1. The point
+    counts are the reference's; each rule integrates every monomial of its degree to the accuracy of 15-digit
+    constants (the degree-3/4 rule included: the reference's own copy of it is damaged, see the class header)."""
+    c = _Rule(degree)
+    assert c.n == REFERENCE_RULE_SIZES[degree - 1]
+    assert abs(c.w.sum() - 2.0) < 1e-13
+    assert np.all(c.r >= -1) and np.all(c.s >= -1) and np.all(c.r + c.s <= 1e-15)     # no point outside the triangle
+    assert _monomial_errors(c, degree) < 5e-13
+
+
+@pytest.mark.parametrize("degree", [29, 30, 33, 40])
+def test_computed_cubature_rule_beyond_the_table_is_exact_to_its_degree(coarse_mesh, degree):
+    """Beyond degree 28 (where the reference indexes past its table): the conical product rule, through the builder."""
+    nodes = dg.TriangleNodesProvisioner(1, coarse_mesh)
+    c = nodes.buildCubatureVolumeMesh(degree)
+    assert np.all(c.w > 0) and np.all(c.r > -1) and np.all(c.s > -1) and np.all(c.r + c.s < 0)
+    assert _monomial_errors(c, degree) < 2e-14
     assert c.NumCubaturePoints == ((degree + 2) // 2) ** 2    # n x n conical product, 2n - 1 >= degree
+    assert _Rule(degree).n == c.NumCubaturePoints
 
 
 @pytest.mark.parametrize("order", [1, 2, 4, 6])

@@ -538,6 +538,24 @@ def test_variant_b_matches_the_reference_function_where_it_degenerates_to_it(cas
     assert abs(s.globalSpeed - (0.8 + np.sqrt(float(d["g"]) * 10.0))) < 1e-12 * s.globalSpeed
 
 
+@pytest.mark.parametrize("tag", ["bed", "bed_drag"])
+@pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N6", "box3x2_N8"])
+def test_variant_b_matches_the_reference_function_over_a_continuous_bed(case, tag):
+    """The HIP variant-B kernels (unrolled at N=3, matrix cores at N=6 and N=8) against the reference's Python RHS
+    over a continuous, non-flat bed: star states computed (and the identity), bed-slope source, RHS2 drag, Coriolis,
+    global speed = c0 (tests/golden/sw2d_rhsB_bed*_*.npz)."""
+    import os
+    from conftest import GOLDEN
+    d = np.load(os.path.join(GOLDEN, f"sw2d_rhsB_{tag}_{case}.npz"))
+    s = solver_from_case(d)
+    s.enableVariantB(d["H"], d["Hx"], d["Hy"], mapO=(), CD=float(d["CD"]), f=float(d["f"]))
+    r = s.computeRHS(d["h"], d["hu"], d["hv"])
+    scale = max(np.abs(d[f"rhs{i}"]).max() for i in (1, 2, 3))
+    for i in range(3):
+        assert np.abs(r[i] - d[f"rhs{i + 1}"]).max() / scale < RHS_TOL
+    assert abs(s.globalSpeed - float(d["c0"])) < 1e-12 * s.globalSpeed
+
+
 @pytest.mark.parametrize("order,shuffle", [(2, 0), (4, 11)])
 def test_variant_b_ssprk2_driver_loop_vs_oracle(order, shuffle):
     """The driver's loop body (main.cpp:211-236): Heun with both evaluations at the old time level,
