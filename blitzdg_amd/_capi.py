@@ -210,6 +210,7 @@ _SIGNATURES = {
     "bdg_sw2d_curved_synchronize": (c_int, [_P]),
     "bdg_sw2d_curved_device_bytes": (c_size_t, [_P]),
     "bdg_sw2d_curved_bytes_per_element": (c_double, [_P]),
+    "bdg_sw2d_curved_form": (c_int, [_P]),
 }
 
 #: every symbol include/blitzdg_hip.h declares (checked by tests/test_capi_symbols.py)

@@ -86,6 +86,11 @@ struct bdg_sw2d_curved {
     Buf<int> gmapP, gmapM, curvedSlot, curvedEls, affineEl;
     Buf<double> cubAffine, cubWref;
     int numAffine = 0;
+    // nodal-trace form (sw2d_curved_nt_kernel.hpp): used when the context has the structure it needs (useNT)
+    bool useNT = false;
+    Buf<double> opsNT, elAffine, gaussWref;
+    Buf<int> nodeP, faceFlags, affineNT;
+    int numAffineNT = 0;
     double g = 9.81, fconst = 0.0, cdconst = 0.0;
     long long stageCount = 0;
     double bytesPerElement = 0.0;
@@ -120,6 +125,10 @@ struct bdg_sw2d_curved {
         p.mmSide = mmSide.p; p.cholSide = cholSide.p; p.curvedEls = curvedEls.p; p.numCurved = numCurved; p.sideLd = sideLd;
         p.affineEl = numAffine ? affineEl.p : nullptr; p.cubAffine = numAffine ? cubAffine.p : nullptr; p.cubWref = cubWref.p;
         p.ops = ops.p; p.filt = filt.p; p.ld = ld; p.K = K; p.ncb = ncb; p.ncub = ncub; p.ng = ng; p.fb = fb; p.g = g;
+        if (useNT) {
+            p.opsNT = opsNT.p; p.nodeP = nodeP.p; p.faceFlags = faceFlags.p; p.gaussWref = gaussWref.p;
+            p.affineEl = numAffineNT ? affineNT.p : nullptr; p.elAffine = numAffineNT ? elAffine.p : nullptr;
+        }
         return p;
     }
 
@@ -129,9 +138,26 @@ struct bdg_sw2d_curved {
         if (filter && !hasFilter) throw arg_error("bdg_sw2d_curved: filter requested but the solver was created without a Filter matrix");
         bdg_dev::CurvedParams p = params();
         p.qin = qin; p.qbase = qbase; p.qout = qout; p.res = res.p; p.rhs = rhs.p; p.ca = ca; p.cb = cb; p.cc = cc;
-        hipOk(kt->gauss(p, stream), "sw2d_curved_gauss_kernel");
-        hipOk(kt->stage(mode, filter, p, stream), "sw2d_curved_stage_kernel");
+        if (useNT) { // one launch: the neighbours' traces are products of their nodal values (no Gauss-trace planes)
+            if (qin == qout) throw arg_error("bdg_sw2d_curved: the nodal-trace kernel cannot update the state it gathers from in place");
+            hipOk(kt->stageNT(mode, filter, p, stream), "sw2d_curved_nt_kernel");
+        } else {
+            hipOk(kt->gauss(p, stream), "sw2d_curved_gauss_kernel");
+            hipOk(kt->stage(mode, filter, p, stream), "sw2d_curved_stage_kernel");
+        }
         hipOk(kt->fixup(mode, filter, p, stream), "sw2d_curved_fixup_kernel");
+    }
+
+    // one LSERK4 stage: res = a res + dt RHS(q); q += b res. The first form updates q in place (it reads neighbours
+    // through the trace planes); the nodal-trace form reads neighbours' nodes from q, so it writes the other buffer
+    // and the two swap roles.
+    void lserkStage(double a, double b, double dt) {
+        if (useNT) {
+            evaluate(bdg_dev::CMODE_LSERK, false, qA.p, nullptr, qB.p, a, b, dt);
+            std::swap(qA.p, qB.p);
+        } else {
+            evaluate(bdg_dev::CMODE_LSERK, false, qA.p, nullptr, qA.p, a, b, dt);
+        }
     }
 
     void stepRk2(double dt, int steps, bool filter) {
@@ -156,6 +182,229 @@ std::vector<double> matmul(const double* A, const double* B, int n, int m, int c
             for (int j = 0; j < c; ++j) C[static_cast<size_t>(i) * c + j] += a * B[static_cast<size_t>(k) * c + j];
         }
     return C;
+}
+
+// Tables of the nodal-trace form (sw2d_curved_nt_kernel.hpp), or useNT = false when the context lacks the structure:
+//  (1) gmapM is the identity; (2) every row block of Interp that belongs to a face is zero outside N + 1 columns (its face
+//  nodes); (3) gmapP pairs whole faces, in the same or in the opposite direction, and the paired faces' interpolation
+//  columns agree at the paired Gauss points under one permutation of their face nodes; (4) a face's Gauss points are all
+//  walls or none; (5) the image fits the kernel's LDS plan. BDG_SW2D_CURVED_GENERAL=1 keeps the first form (A/B, cross-check).
+void buildNodalTraceTables(bdg_sw2d_curved& s, const bdg_sw2d_curved_desc& d, const std::vector<int>& slotOf) {
+    s.useNT = false;
+    if (std::getenv("BDG_SW2D_CURVED_GENERAL") || !s.identityM) return;
+    const bdg_dev::CurvedKernelTable* kt = s.kt;
+    const int N = s.N, Np = s.Np, K = s.K, Ncub = s.ncub, NG = s.ng, NG3 = 3 * NG, ncb = s.ncb, fb = s.fb, Nfp = N + 1;
+    const int CR = 16 * ncb, KV = kt->KV, MT = kt->MT;
+    const long long ld = s.ld;
+    if (!kt->ntFits(ncb, fb, d.Filter != nullptr)) return;
+    if (4ll * CR * ld * 8 > 4294967295LL) return; // the cubature planes behind ONE descriptor
+    int off[5];
+    kt->ntOffsets(ncb, fb, off);
+    const int VCH = off[0], SCH = off[1], KE = off[2], offSurf = off[3], offMass = off[4];
+    const double* I = d.gaussInterp; // (3 NG, Np)
+    // (2) face nodes
+    std::vector<std::vector<int>> faceNodes(3);
+    for (int f = 0; f < 3; ++f) {
+        for (int m = 0; m < Np; ++m) {
+            double big = 0.0;
+            for (int ig = 0; ig < NG; ++ig) big = std::max(big, std::fabs(I[static_cast<size_t>(f * NG + ig) * Np + m]));
+            if (big > 1e-9) faceNodes[f].push_back(m);
+            else if (big > 1e-12) return; // neither a face node nor nothing
+        }
+        if (static_cast<int>(faceNodes[f].size()) != Nfp) return;
+    }
+    auto IF = [&](int f, int ig, int i) { return I[static_cast<size_t>(f * NG + ig) * Np + faceNodes[f][i]]; };
+    // (3) node pairing of (f, f2, direction): perm[i] = i2 with IF(f, ig, i) == IF(f2, ig2(ig), i2) for every ig
+    std::vector<int> perm(static_cast<size_t>(18) * Nfp, -1);
+    std::vector<int> permState(18, 0); // 0 not tried, 1 found, -1 none
+    auto pairing = [&](int f, int f2, int rev) -> const int* {
+        const int id = (f * 3 + f2) * 2 + rev;
+        int* out = perm.data() + static_cast<size_t>(id) * Nfp;
+        if (permState[id] == 0) {
+            std::vector<char> used(Nfp, 0);
+            bool ok = true;
+            for (int i = 0; i < Nfp && ok; ++i) {
+                int found = -1;
+                for (int i2 = 0; i2 < Nfp && found < 0; ++i2) {
+                    if (used[i2]) continue;
+                    double worst = 0.0;
+                    for (int ig = 0; ig < NG; ++ig) worst = std::max(worst, std::fabs(IF(f, ig, i) - IF(f2, rev ? NG - 1 - ig : ig, i2)));
+                    if (worst < 1e-11) found = i2;
+                }
+                if (found < 0) ok = false;
+                else { used[found] = 1; out[i] = found; }
+            }
+            permState[id] = ok ? 1 : -1;
+        }
+        return permState[id] == 1 ? out : nullptr;
+    };
+    // (3), (4) per face of every element
+    const int rowsP = 3 * KE * 4;
+    std::vector<int> nodeP(static_cast<size_t>(rowsP) * K), flags(static_cast<size_t>(ld), 0), wallCount(static_cast<size_t>(3) * K, 0);
+    for (int i = 0; i < d.num_wall; ++i) {
+        const int w = d.gmapW[i];
+        ++wallCount[static_cast<size_t>(w / NG3) * 3 + (w % NG3) / NG];
+    }
+    bool structured = true;
+    for (int k = 0; k < K && structured; ++k)
+        for (int f = 0; f < 3 && structured; ++f) {
+            const int* gp = d.gmapP + static_cast<size_t>(k) * NG3 + f * NG;
+            const int k2 = gp[0] / NG3, f2 = (gp[0] % NG3) / NG, l0 = gp[0] % NG;
+            int rev;
+            if (l0 == 0 && (NG == 1 || gp[NG - 1] % NG == NG - 1)) rev = 0;
+            else if (l0 == NG - 1) rev = 1;
+            else { structured = false; break; }
+            for (int ig = 0; ig < NG; ++ig)
+                if (gp[ig] != k2 * NG3 + f2 * NG + (rev ? NG - 1 - ig : ig)) structured = false;
+            const int* pm = structured ? pairing(f, f2, rev) : nullptr;
+            if (!pm) { structured = false; break; }
+            const int wc = wallCount[static_cast<size_t>(k) * 3 + f];
+            if (wc != 0 && wc != NG) { structured = false; break; }
+            if (wc) flags[k] |= 1 << f;
+            for (int i = 0; i < KE * 4; ++i)
+                nodeP[static_cast<size_t>(f * KE * 4 + i) * K + k] =
+                    i < Nfp ? static_cast<int>(faceNodes[f2][pm[i]] * ld + k2) : k; // padding rows: an own node (the column of GE is zero)
+        }
+    if (!structured) return;
+    for (long long k = K; k < ld; ++k) flags[k] = flags[K - 1];
+
+    hipStream_t st = s.stream;
+    // ---- straight-sided elements: the cubature numbers of the first form's test, the Gauss geometry and the nodal Jacobian
+    std::vector<int> aff(static_cast<size_t>(ld), 0);
+    std::vector<double> ea(static_cast<size_t>(14) * K, 0.0), gwHalf(static_cast<size_t>(16) * fb, 0.0), wref(static_cast<size_t>(CR), 0.0);
+    int count = 0;
+    if (!std::getenv("BDG_SW2D_CURVED_NO_AFFINE")) {
+        const double* geo[4] = {d.cubrx, d.cubry, d.cubsx, d.cubsy};
+        auto straight = [&](int k, const double* wr, const double* gw, double* e) { // fills e[0..13]; false: not straight
+            if (slotOf[k] >= 0) return false;                                       // elements of curvedEls keep the general path
+            double scale = 0.0;
+            for (int t = 0; t < 4; ++t) scale = std::max(scale, std::fabs(geo[t][k]));
+            for (int t = 0; t < 4; ++t)
+                for (int i = 1; i < Ncub; ++i)
+                    if (std::fabs(geo[t][static_cast<size_t>(i) * K + k] - geo[t][k]) > 1e-10 * scale) return false;
+            const double j0 = d.J[k];
+            for (int m = 1; m < Np; ++m)
+                if (std::fabs(d.J[static_cast<size_t>(m) * K + k] - j0) > 1e-10 * std::fabs(j0)) return false;
+            for (int f = 0; f < 3; ++f) {
+                const size_t r0 = static_cast<size_t>(f) * NG * K + k;
+                for (int ig = 1; ig < NG; ++ig)
+                    if (std::fabs(d.gaussnx[r0 + static_cast<size_t>(ig) * K] - d.gaussnx[r0]) > 1e-10 ||
+                        std::fabs(d.gaussny[r0 + static_cast<size_t>(ig) * K] - d.gaussny[r0]) > 1e-10) return false;
+            }
+            if (!wr) return true; // (the search for the reference element stops here)
+            const double ratio = d.cubW[k] / wr[0];
+            if (!(ratio > 0.0)) return false;
+            for (int i = 1; i < Ncub; ++i)
+                if (std::fabs(d.cubW[static_cast<size_t>(i) * K + k] - ratio * wr[i]) > 1e-10 * std::fabs(ratio * wr[i])) return false;
+            for (int t = 0; t < 4; ++t) e[t] = ratio * geo[t][k];
+            for (int f = 0; f < 3; ++f) {
+                const size_t r0 = static_cast<size_t>(f) * NG * K + k;
+                const double sf = d.gaussW[r0] / gw[0];
+                if (!(sf > 0.0)) return false;
+                for (int ig = 1; ig < NG; ++ig)
+                    if (std::fabs(d.gaussW[r0 + static_cast<size_t>(ig) * K] - sf * gw[ig]) > 1e-10 * std::fabs(sf * gw[ig])) return false;
+                e[4 + 3 * f] = d.gaussnx[r0]; e[5 + 3 * f] = d.gaussny[r0]; e[6 + 3 * f] = sf;
+            }
+            e[13] = 1.0 / j0;
+            return true;
+        };
+        int kref = -1;
+        for (int k = 0; k < K && kref < 0; ++k)
+            if (straight(k, nullptr, nullptr, nullptr) && d.cubW[k] > 0.0 && d.gaussW[k] > 0.0) kref = k;
+        if (kref >= 0) {
+            std::vector<double> gw(static_cast<size_t>(NG));
+            for (int i = 0; i < Ncub; ++i) wref[i] = d.cubW[static_cast<size_t>(i) * K + kref];
+            for (int ig = 0; ig < NG; ++ig) { gw[ig] = d.gaussW[static_cast<size_t>(ig) * K + kref]; gwHalf[ig] = 0.5 * gw[ig]; }
+            std::atomic<int> counted{0};
+            blitzdg::detail::parallelChunks(K, [&](int kBegin, int kEnd) {
+                int mine = 0;
+                double e[14];
+                for (int k = kBegin; k < kEnd; ++k) {
+                    if (!straight(k, wref.data(), gw.data(), e)) continue;
+                    aff[k] = 1;
+                    for (int i = 0; i < 14; ++i) ea[static_cast<size_t>(i) * K + k] = e[i];
+                    ++mine;
+                }
+                counted += mine;
+            });
+            count = counted;
+        }
+    }
+    s.numAffineNT = count;
+    for (long long k = K; k < ld; ++k) aff[k] = aff[K - 1];
+    s.affineNT.alloc(static_cast<size_t>(ld), s.bytes, st);
+    hipOk(hipMemcpyAsync(s.affineNT.p, aff.data(), aff.size() * sizeof(int), hipMemcpyHostToDevice, st), "affine flags upload");
+    s.elAffine.alloc(static_cast<size_t>(14) * ld, s.bytes, st);
+    s.uploadRows(ea.data(), s.elAffine.p, 14);
+    if (!s.cubWref.p) { // (the first form's reference weights when it found straight elements: the same numbers)
+        s.cubWref.alloc(wref.size(), s.bytes, st);
+        hipOk(hipMemcpyAsync(s.cubWref.p, wref.data(), wref.size() * sizeof(double), hipMemcpyHostToDevice, st), "Wref upload");
+    }
+    s.gaussWref.alloc(gwHalf.size(), s.bytes, st);
+    hipOk(hipMemcpyAsync(s.gaussWref.p, gwHalf.data(), gwHalf.size() * sizeof(double), hipMemcpyHostToDevice, st), "gauss Wref upload");
+    s.faceFlags.alloc(static_cast<size_t>(ld), s.bytes, st);
+    hipOk(hipMemcpyAsync(s.faceFlags.p, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice, st), "face flags upload");
+    s.nodeP.alloc(static_cast<size_t>(rowsP) * ld, s.bytes, st);
+    s.uploadRows(nodeP.data(), s.nodeP.p, rowsP);
+
+    // ---- operator image (CurvedOpsNT)
+    std::vector<double> img(static_cast<size_t>(kt->ntTiles(ncb, fb)) * 64, 0.0);
+    auto at = [&](int tile, int l) -> double& { return img[static_cast<size_t>(tile) * 64 + l]; };
+    std::vector<double> Vt(static_cast<size_t>(Np) * Np);
+    for (int i = 0; i < Np; ++i)
+        for (int jj = 0; jj < Np; ++jj) Vt[static_cast<size_t>(i) * Np + jj] = d.V[static_cast<size_t>(jj) * Np + i];
+    const std::vector<double> M = matmul(d.V, Vt.data(), Np, Np, Np);
+    std::vector<double> MF;
+    if (d.Filter) MF = matmul(d.Filter, M.data(), Np, Np, Np);
+    for (int l = 0; l < 64; ++l) {
+        const int i = l & 15, sc = l >> 4;
+        for (int rb = 0; rb < ncb; ++rb) {
+            const int base = rb * VCH;
+            for (int t = 0; t < KV; ++t) {
+                const int row = 16 * rb + i, m = 4 * t + sc;
+                if (row < Ncub && m < Np) at(base + t, l) = d.cubV[static_cast<size_t>(row) * Np + m];
+            }
+            for (int r = 0; r < MT; ++r)
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int node = 16 * r + i, cp = 16 * rb + 4 * reg + sc;
+                    if (node < Np && cp < Ncub) {
+                        at(base + KV + r * 4 + reg, l) = d.cubDr[static_cast<size_t>(cp) * Np + node];
+                        at(base + KV + 4 * MT + r * 4 + reg, l) = d.cubDs[static_cast<size_t>(cp) * Np + node];
+                    }
+                }
+        }
+        for (int gb = 0; gb < 3 * fb; ++gb) {
+            const int base = offSurf + gb * SCH, f = gb / fb, b = gb % fb;
+            for (int t = 0; t < KV; ++t) {
+                const int local = 16 * b + i, m = 4 * t + sc;
+                if (local < NG && m < Np) at(base + t, l) = I[static_cast<size_t>(f * NG + local) * Np + m];
+            }
+            for (int t2 = 0; t2 < KE; ++t2) {
+                const int local = 16 * b + i, fn = 4 * t2 + sc;
+                if (local < NG && fn < Nfp) at(base + KV + t2, l) = IF(f, local, fn);
+            }
+            for (int r = 0; r < MT; ++r)
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int node = 16 * r + i, local = 16 * b + 4 * reg + sc;
+                    if (node < Np && local < NG) at(base + KV + KE + r * 4 + reg, l) = -I[static_cast<size_t>(f * NG + local) * Np + node];
+                }
+        }
+        for (int r = 0; r < MT; ++r)
+            for (int t = 0; t < KV; ++t) {
+                const int node = 16 * r + i, m = 4 * t + sc;
+                if (node < Np && m < Np) {
+                    at(offMass + r * KV + t, l) = M[static_cast<size_t>(node) * Np + m];
+                    if (d.Filter) {
+                        at(offMass + MT * KV + r * KV + t, l) = MF[static_cast<size_t>(node) * Np + m];
+                        at(offMass + 2 * MT * KV + r * KV + t, l) = d.Filter[static_cast<size_t>(node) * Np + m];
+                    }
+                }
+            }
+    }
+    s.opsNT.alloc(img.size(), s.bytes, st);
+    hipOk(hipMemcpyAsync(s.opsNT.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice, st), "ops upload");
+    hipOk(hipStreamSynchronize(st), "nodal-trace tables sync");
+    s.useNT = true;
 }
 
 bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
@@ -433,6 +682,7 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         }
         hipOk(hipStreamSynchronize(st), "ops sync");
     }
+    buildNodalTraceTables(*s, d, slotOf);
     // compulsory bytes of one RHS evaluation per element: state in, RHS out, geometry, maps, traces out and in (twice: both sides)
     // state in, RHS out, cubature geometry (4 Ncub per general element, 4 per straight one), Gauss geometry, 1/J, sources,
     // state again in the trace kernel, traces out and in (the exterior side; the interior side too when gmapM is not the identity)
@@ -441,6 +691,13 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
                                 (d.zy ? Np : 0) + (d.coriolis ? Np : 0) + (d.drag ? Np : 0) + 4 * Np +
                                 (identityM ? 2 : 3) * 4 * NG3) +
                          4.0 * (NG3 * (identityM ? 1 : 2) + 2);
+    if (s->useNT) { // state in, update in / out, the neighbours' face nodes, node map + flags, geometry (14 numbers on straight elements), sources
+        const double fa = static_cast<double>(s->numAffineNT) / K;
+        const int Nfp = s->N + 1, KE = (Nfp + 3) / 4;
+        s->bytesPerElement = 8.0 * (4 * Np + 4 * Np + 4 * 3 * Nfp + (1.0 - fa) * (4 * Ncub + 3 * NG3 + Np) + fa * 14 + (d.zx ? Np : 0) +
+                                    (d.zy ? Np : 0) + (d.coriolis ? Np : 0) + (d.drag ? Np : 0)) +
+                             4.0 * (3 * KE * 4 + 3);
+    }
     return s.release();
 }
 
@@ -517,8 +774,7 @@ int bdg_sw2d_curved_lserk4_stages(bdg_sw2d_curved* s, double dt, int num_stages)
             const int st = static_cast<int>(s->stageCount % blitzdg::LSERK4::numStages);
             // res = a res + dt RHS(q); q += b res   (reference src/advec1d/main.cpp:92-102), in place: only own
             // elements are read from q by the stage kernel, the neighbours' traces come from gq
-            s->evaluate(bdg_dev::CMODE_LSERK, false, s->qA.p, nullptr, s->qA.p, blitzdg::LSERK4::rk4a[st],
-                        blitzdg::LSERK4::rk4b[st], dt);
+            s->lserkStage(blitzdg::LSERK4::rk4a[st], blitzdg::LSERK4::rk4b[st], dt);
             ++s->stageCount;
         }
     });
@@ -549,5 +805,6 @@ int bdg_sw2d_curved_synchronize(bdg_sw2d_curved* s) {
 
 size_t bdg_sw2d_curved_device_bytes(const bdg_sw2d_curved* s) { return s ? s->bytes : 0; }
 double bdg_sw2d_curved_bytes_per_element(const bdg_sw2d_curved* s) { return s ? s->bytesPerElement : 0.0; }
+int bdg_sw2d_curved_form(const bdg_sw2d_curved* s) { return s ? (s->useNT ? 1 : 0) : -1; }
 
 } // extern "C"

@@ -69,6 +69,12 @@ struct CurvedParams {
     const double* cubAffine; // 4 rows of ld: the element's numbers c with (W rx, W ry, W sx, W sy)[i] = cubWref[i] * c
     const double* cubWref;   // CR: W at the cubature points of a reference straight element (zero padded)
     const double* ops;    // operator image (CurvedOps layout), 64 doubles per tile
+    // nodal-trace form (sw2d_curved_nt_kernel.hpp); nullptr / unused in the first form
+    const double* opsNT;     // operator image in CurvedOpsNT layout
+    const int* nodeP;        // (3 * KE * 4, ld): offset row * ld + k of the neighbour's node at my face node (face f, node i) at row f * KE * 4 + i
+    const int* faceFlags;    // ld: bit f set = face f is a wall
+    const double* elAffine;  // (14, ld): straight elements: W rx, W ry, W sx, W sy factors; nx, ny, W factor per face; 1 / J
+    const double* gaussWref; // 16 fb: HALF the Gauss weights of a reference straight face (zero padded)
     const double* filt;   // (Np, Np) row-major filter for the fix-up kernel, or nullptr
     long long ld;
     int K;
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
         const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
         const bool live = kTrue <= kLast;
         const unsigned k = live ? kTrue : kLast; // padding lanes recompute the last element, store nothing
-        const unsigned k8 = k * 8u, k4 = k * 4u, v8 = (q * static_cast<unsigned>(ld) + k) * 8u, v4 = v8 >> 1;
+        const unsigned k8 = k * 8u, v8 = (q * static_cast<unsigned>(ld) + k) * 8u, v4 = v8 >> 1;
         // vector offset of node row 4 t + q (out of range on the padding rows of the last k-step)
         auto nodeOff = [&](int t) -> unsigned {
             if constexpr (Np % 4 != 0) {
@@ -639,6 +645,11 @@ struct CurvedKernelTable {
     hipError_t (*gauss)(const CurvedParams& p, hipStream_t stream);
     hipError_t (*stage)(int mode, bool filter, const CurvedParams& p, hipStream_t stream);
     hipError_t (*fixup)(int mode, bool filter, const CurvedParams& p, hipStream_t stream);
+    // nodal-trace form
+    int (*ntTiles)(int ncb, int fb);                  // tiles of its image
+    void (*ntOffsets)(int ncb, int fb, int* off);     // VCH, SCH, KE, offSurf(0), offMass
+    bool (*ntFits)(int ncb, int fb, bool filter);     // its LDS plan fits a workgroup
+    hipError_t (*stageNT)(int mode, bool filter, const CurvedParams& p, hipStream_t stream);
 };
 const CurvedKernelTable* curved_kernel_table(int order); // nullptr if the order is not compiled in
 

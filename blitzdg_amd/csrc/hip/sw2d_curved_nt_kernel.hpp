@@ -1,0 +1,403 @@
+// sw2d_curved_nt_kernel.hpp -- curved / over-integrated shallow-water RHS, "nodal-trace" form (round 3).
+//
+// Same mathematics as sw2d_curved_kernel.hpp (reference swhelpers/rhs.py:6-176), one launch instead of two per
+// evaluation and about half the bytes. What changed, and why it is the same function:
+//
+//  * No Gauss-trace planes. The first form materialised gq = Interp q of every element (its own kernel, 12 NGauss
+//    doubles written and read back per element) because the exterior trace of a Gauss point lives in the neighbour.
+//    But the trace of a degree-N polynomial on an edge is fixed by its N+1 edge nodes: the rows of gauss_ctx.Interp
+//    that belong to face f are zero outside Fmask(:, f). So the exterior trace at my Gauss points is MY face block of
+//    Interp applied to the neighbour's values at the nodes that coincide with my face nodes:
+//        gP(face f) = IF_f (NG x Nfp)  *  q[nodeP(f, :)],     nodeP(f, i) = the neighbour's node at my face node i
+//    -- 3 Nfp gathered doubles per field instead of 3 NG written + 3 NG read, and the gathered rows are the state rows
+//    the neighbouring tile streams anyway (L2). nodeP is derived at creation from gmapP (any map that pairs whole
+//    faces: interior, wall, periodic) and from Interp itself (the face nodes are the columns that are not zero; the
+//    node pairing of two faces is the permutation that makes their interpolation columns agree at the paired Gauss
+//    points). A context that does not have this structure (a rewired gmapM, a map that pairs single points across
+//    different faces, an Interp with entries off the face) keeps the first form (sw2d_curved_kernel.hpp).
+//  * Straight-sided tiles read 14 numbers per element: W rx .. W sy = wref * c (as before), and now also the Gauss
+//    geometry -- nx, ny constant per face, W = gwref * s_f -- and 1 / J, instead of 9 NGauss + Np doubles.
+//  * Orders 7 and 8: the operator image (>= 195 KB) does not fit LDS. The volume term's tiles are streamed through a
+//    double buffer, one 16-cubature-row chunk at a time, by the four waves of a workgroup in lockstep (one barrier
+//    per chunk; the next chunk's loads are in flight while the current one is multiplied); surface and mass tiles
+//    stay resident. The first form read every A tile from L2 per wave and per tile.
+//
+// Layout of lanes, operands and accumulators: as described at the top of sw2d_curved_kernel.hpp.
+#pragma once
+#include "sw2d_curved_kernel.hpp"
+
+namespace bdg_dev {
+
+// Operator image of the nodal-trace kernel: zero-padded 16 x 4 A tiles, 64 doubles each, entry l of a tile =
+// A[row l & 15][step column l >> 4], grouped so that what one phase needs is contiguous:
+//   volume chunk rb (VCH tiles):   Vc[t]            row 16 rb + i = cubature point, column 4 t + s = node
+//                                  DrT[r][reg]      row 16 r + i = node, column s <-> cubature point 16 rb + 4 reg + s
+//                                  DsT[r][reg]
+//   surface block gb = f FB + b (SCH tiles):
+//                                  GI[t]            row = Gauss row 16 b + i of face f, column 4 t + s = node (Interp)
+//                                  GE[t2]           same rows, column 4 t2 + s = FACE node i of face f (Interp(:, Fmask(i, f)))
+//                                  IT[r][reg]       row 16 r + i = node, column s <-> Gauss row 16 b + 4 reg + s (-Interp^T)
+//   mass (3 MT KV tiles):          M[r][t] = V V^T,  MF[r][t] = Filter V V^T,  F[r][t] = Filter
+template <int N>
+struct CurvedOpsNT {
+    static constexpr int Np = (N + 1) * (N + 2) / 2;
+    static constexpr int Nfp = N + 1;
+    static constexpr int KV = (Np + 3) / 4;
+    static constexpr int MT = (Np + 15) / 16;
+    static constexpr int KE = (Nfp + 3) / 4;
+    static constexpr int VCH = KV + 8 * MT;
+    static constexpr int SCH = KV + KE + 4 * MT;
+    __host__ __device__ static constexpr int offVol(int rb) { return rb * VCH; }
+    __host__ __device__ static constexpr int offSurf(int ncb, int gb) { return ncb * VCH + gb * SCH; }
+    __host__ __device__ static constexpr int offMass(int ncb, int fb) { return ncb * VCH + 3 * fb * SCH; }
+    __host__ __device__ static constexpr int tiles(int ncb, int fb) { return offMass(ncb, fb) + 3 * MT * KV; }
+};
+
+// STREAM = 0: whole image resident in LDS. STREAM = 1: volume chunks through a double buffer, the workgroup's waves in
+// lockstep; resident: surface blocks, the mass tiles this launch uses (M or MF, and F when FILTER).
+template <int N, int MODE, bool FILTER, int STREAM, int FB, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const CurvedParams p) {
+    using O = CurvedOpsNT<N>;
+    constexpr int Np = O::Np, KV = O::KV, MT = O::MT, KE = O::KE, VCH = O::VCH, SCH = O::SCH;
+    extern __shared__ double sOps[];
+    const int ncb = p.ncb;
+    constexpr int fb = FB;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+    // ---- LDS map (in tiles of 64 doubles): [stream buffers 2 VCH] [resident tiles] [wref 16 ncb] [gwref 16 FB]
+    const int imgSurf = O::offSurf(ncb, 0), imgMass = O::offMass(ncb, fb);
+    const int nSurf = 3 * fb * SCH;
+    constexpr int massTiles = MT * KV;
+    // resident base (tile index inside LDS) of the surface blocks, of the mass tiles and of the filter tiles
+    const int ldsSurf = STREAM ? 2 * VCH : imgSurf;
+    const int ldsMass = STREAM ? ldsSurf + nSurf : imgMass + (FILTER ? massTiles : 0);
+    const int ldsF = STREAM ? ldsMass + massTiles : imgMass + 2 * massTiles;
+    const int ldsTiles = STREAM ? ldsMass + (FILTER ? 2 : 1) * massTiles : O::tiles(ncb, fb);
+    const int wrefAt = ldsTiles * 64, gwrefAt = wrefAt + 16 * ncb;
+
+    auto copyTiles = [&](const double* src, int dstTile, int ntile) { // all of a thread's 16-byte pieces of a batch in flight
+        const f64x2* __restrict__ s2 = reinterpret_cast<const f64x2*>(src);
+        f64x2* __restrict__ d2 = reinterpret_cast<f64x2*>(sOps + static_cast<size_t>(dstTile) * 64);
+        const int pairs = ntile * 32, nthreads = static_cast<int>(blockDim.x);
+        for (int b = threadIdx.x; b < pairs; b += 8 * nthreads) {
+            f64x2 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (b + i * nthreads < pairs) v[i] = s2[b + i * nthreads];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (b + i * nthreads < pairs) d2[b + i * nthreads] = v[i];
+        }
+    };
+    if constexpr (STREAM) {
+        copyTiles(p.opsNT + static_cast<size_t>(imgSurf) * 64, ldsSurf, nSurf);
+        copyTiles(p.opsNT + static_cast<size_t>(imgMass + (FILTER ? massTiles : 0)) * 64, ldsMass, massTiles);
+        if constexpr (FILTER) copyTiles(p.opsNT + static_cast<size_t>(imgMass + 2 * massTiles) * 64, ldsF, massTiles);
+        copyTiles(p.opsNT, 0, VCH); // chunk 0 of the first tile
+    } else {
+        copyTiles(p.opsNT, 0, O::tiles(ncb, fb));
+    }
+    for (int t = threadIdx.x; t < 16 * ncb; t += blockDim.x) sOps[wrefAt + t] = p.cubWref ? p.cubWref[t] : 0.0;
+    for (int t = threadIdx.x; t < 16 * fb; t += blockDim.x) sOps[gwrefAt + t] = p.gaussWref ? p.gaussWref[t] : 0.0;
+    __syncthreads();
+
+    const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
+    auto L = [&](int tile) -> double { return sOps[tile * 64 + static_cast<int>(lane)]; };
+
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, gplane = 48ll * fb * ld, cplane = 16ll * ncb * ld;
+    const unsigned ld8 = static_cast<unsigned>(ld) * 8u, ld4 = static_cast<unsigned>(ld) * 4u;
+    const unsigned planeB = static_cast<unsigned>(plane * 8), gplaneB = static_cast<unsigned>(gplane * 8),
+                   cplaneB = static_cast<unsigned>(cplane * 8);
+    const unsigned ncoef = 1u + (p.zx ? 1u : 0u) + (p.zy ? 1u : 0u) + (p.fcor ? 1u : 0u) + (p.cd ? 1u : 0u);
+    const __amdgpu_buffer_rsrc_t rq = cplane_rsrc(p.qin, 4u * planeB),
+                                 rold = cplane_rsrc(MODE == CMODE_LSERK ? p.res : (MODE == CMODE_COMBINE ? p.qbase : p.qin), 4u * planeB),
+                                 rout = cplane_rsrc(MODE == CMODE_RHS ? p.rhs : p.qout, 4u * planeB),
+                                 rgg = cplane_rsrc(p.gaussG, 3u * gplaneB);
+    const __amdgpu_buffer_rsrc_t rcub = cplane_rsrc(p.cubG, 4u * cplaneB); // read on curved / mixed tiles only (< 4 GiB: checked at creation)
+    const __amdgpu_buffer_rsrc_t rnodeP = cplane_rsrc(p.nodeP, static_cast<unsigned>(3 * KE * 4) * ld4),
+                                 rcoef = cplane_rsrc(p.rJ, ncoef * planeB), // rJ [, zx, zy, fcor, cd]: planes of ONE allocation
+                                 raff = cplane_rsrc(p.elAffine ? p.elAffine : p.rJ, 14u * ld8);
+    const unsigned soZx = p.zx ? static_cast<unsigned>((p.zx - p.rJ) * 8) : 0u, soZy = p.zy ? static_cast<unsigned>((p.zy - p.rJ) * 8) : 0u,
+                   soFc = p.fcor ? static_cast<unsigned>((p.fcor - p.rJ) * 8) : 0u, soCd = p.cd ? static_cast<unsigned>((p.cd - p.rJ) * 8) : 0u;
+    const double g = p.g;
+    const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u;
+    unsigned tile, tileEnd;
+    curved_wave_tiles(ntiles, tile, tileEnd);
+    // lockstep form: every wave of the workgroup makes the same number of passes (a wave without a tile only keeps the
+    // barriers and the chunk copies company)
+    const unsigned nwavesAll = gridDim.x * (blockDim.x >> 6);
+    const unsigned passes = STREAM ? (ntiles + nwavesAll - 1u) / nwavesAll : (tileEnd > tile ? tileEnd - tile : 0u);
+    int phase = 0; // stream buffer that holds the chunk about to be used
+
+    for (unsigned pass = 0; pass < passes; ++pass, ++tile) {
+        const bool act = tile < tileEnd;
+        const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
+        const bool live = act && kTrue <= kLast;
+        const unsigned k = (act && kTrue <= kLast) ? kTrue : kLast; // padding lanes recompute the last element, store nothing
+        const unsigned k8 = k * 8u, v8 = (q * static_cast<unsigned>(ld) + k) * 8u, v4 = v8 >> 1;
+        auto nodeOff = [&](int t) -> unsigned { // vector offset of node row 4 t + q (out of range on the padding rows of the last k-step)
+            if constexpr (Np % 4 != 0) {
+                if (t == KV - 1) return (4 * (KV - 1) + static_cast<int>(q) < Np) ? v8 : 0xfffffff8u;
+            }
+            return v8;
+        };
+
+        // ---- own nodal state in operand layout: node m = 4 t + q (0 on padding rows)
+        double qB[4][KV];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < KV; ++t) qB[c][t] = cbld_f64(rq, nodeOff(t), static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8);
+        // straight-sided tile? (one ballot; padding lanes repeat the last element)
+        bool affTile = false;
+        double ea[14];
+#pragma unroll
+        for (int i = 0; i < 14; ++i) ea[i] = 0.0;
+        if (p.elAffine) {
+            affTile = __all(p.affineEl[k] != 0);
+            if (affTile) {
+#pragma unroll
+                for (int i = 0; i < 14; ++i) ea[i] = cbld_f64(raff, k8, static_cast<unsigned>(i) * ld8);
+            }
+        }
+        const int wallBits = p.faceFlags[k];
+        // the neighbours' nodes at my face nodes: face node i = 4 t2 + q of face f (rows beyond Nfp point at an own node:
+        // the matching column of GE is zero)
+        int idxP[3][KE];
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int t2 = 0; t2 < KE; ++t2) idxP[f][t2] = cbld_i32(rnodeP, v4, static_cast<unsigned>(f * KE * 4 + 4 * t2) * ld4);
+
+        cmfma_t acc[4][MT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) acc[c][r] = cmfma_zero();
+
+        // ---- volume term, 16 cubature points at a time
+        for (int rb = 0; rb < ncb; ++rb) {
+            int base; // LDS tile index of this chunk
+            f64x2 pre[(VCH * 32 + 255) / 256];
+            if constexpr (STREAM) {
+                base = phase * VCH;
+                // request the next chunk (this tile's rb + 1, or chunk 0 for the next pass) before the products
+                const int nextRb = rb + 1 < ncb ? rb + 1 : 0;
+                const f64x2* __restrict__ s2 = reinterpret_cast<const f64x2*>(p.opsNT + static_cast<size_t>(O::offVol(nextRb)) * 64);
+#pragma unroll
+                for (int i = 0; i < (VCH * 32 + 255) / 256; ++i) {
+                    const int at = static_cast<int>(threadIdx.x) + i * 256;
+                    if (at < VCH * 32) pre[i] = s2[at];
+                }
+            } else {
+                base = O::offVol(rb);
+            }
+            if (act) {
+                cmfma_t cv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cv[c] = cmfma_zero();
+#pragma unroll
+                for (int t = 0; t < KV; ++t) {
+                    const double a = L(base + t);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], cv[c], 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) { // 4 cubature points of this lane = contraction step reg of DrT / DsT
+                    const int row = 16 * rb + static_cast<int>(q) + 4 * reg;
+                    const unsigned so = static_cast<unsigned>(16 * rb + 4 * reg) * ld8;
+                    double wrx, wry, wsx, wsy;
+                    if (affTile) { // rule weight (times a reference Jacobian) of this point, the element's four numbers
+                        const double w = sOps[wrefAt + row]; // zero on padding rows
+                        wrx = w * ea[0]; wry = w * ea[1]; wsx = w * ea[2]; wsy = w * ea[3];
+                    } else {
+                        wrx = cbld_f64(rcub, v8, so); wry = cbld_f64(rcub, v8, cplaneB + so);
+                        wsx = cbld_f64(rcub, v8, 2u * cplaneB + so); wsy = cbld_f64(rcub, v8, 3u * cplaneB + so);
+                    }
+                    const bool valid = row < p.ncub;
+                    const CurvedFlux fl = curved_fluxes(valid ? cv[0][reg] : 1.0, cv[1][reg], cv[2][reg], cv[3][reg], g);
+                    double tr[4], ts[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        tr[c] = wrx * fl.F[c] + wry * fl.G[c];
+                        ts[c] = wsx * fl.F[c] + wsy * fl.G[c];
+                    }
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        const double aDr = L(base + KV + r * 4 + reg), aDs = L(base + KV + 4 * MT + r * 4 + reg);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDr, tr[c], acc[c][r], 0, 0, 0);
+                            acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDs, ts[c], acc[c][r], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if constexpr (STREAM) {
+                f64x2* __restrict__ d2 = reinterpret_cast<f64x2*>(sOps + static_cast<size_t>((phase ^ 1) * VCH) * 64);
+#pragma unroll
+                for (int i = 0; i < (VCH * 32 + 255) / 256; ++i) {
+                    const int at = static_cast<int>(threadIdx.x) + i * 256;
+                    if (at < VCH * 32) d2[at] = pre[i];
+                }
+                __syncthreads();
+                phase ^= 1;
+            }
+        }
+        if (!act) continue; // (lockstep form: nothing but barriers above for a wave without a tile)
+
+        // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            // the neighbour's values at my face nodes (operand layout of GE: face node 4 t2 + q)
+            double qP[4][KE];
+#pragma unroll
+            for (int t2 = 0; t2 < KE; ++t2) {
+                const unsigned oP = static_cast<unsigned>(idxP[f][t2]) * 8u;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qP[c][t2] = cbld_f64(rq, oP, static_cast<unsigned>(c) * planeB);
+            }
+            const bool wall = (wallBits >> f) & 1;
+            double lam = 0.0;
+            double ef[FB][4][4], dj[FB][4][4];
+#pragma unroll
+            for (int b = 0; b < FB; ++b) {
+                const int gb = f * FB + b, sbase = ldsSurf + gb * SCH;
+                cmfma_t gM[4], gP[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { gM[c] = cmfma_zero(); gP[c] = cmfma_zero(); }
+#pragma unroll
+                for (int t = 0; t < KV; ++t) {
+                    const double a = L(sbase + t);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], gM[c], 0, 0, 0);
+                }
+#pragma unroll
+                for (int t2 = 0; t2 < KE; ++t2) {
+                    const double a = L(sbase + KV + t2);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gP[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qP[c][t2], gP[c], 0, 0, 0);
+                }
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int local = 16 * b + static_cast<int>(q) + 4 * reg;
+                    const bool valid = local < p.ng;
+                    double nx, ny, hW;
+                    if (affTile) {
+                        nx = ea[4 + 3 * f]; ny = ea[5 + 3 * f];
+                        hW = sOps[gwrefAt + local] * ea[6 + 3 * f]; // gwref holds half the reference weights; zero on padding rows
+                    } else {
+                        const unsigned so8 = static_cast<unsigned>(16 * gb + 4 * reg) * ld8;
+                        nx = cbld_f64(rgg, v8, so8); ny = cbld_f64(rgg, v8, gplaneB + so8);
+                        hW = 0.5 * cbld_f64(rgg, v8, 2u * gplaneB + so8); // zero on padding rows
+                    }
+                    double hM = gM[0][reg], huM = gM[1][reg], hvM = gM[2][reg], hNM = gM[3][reg];
+                    double hP = gP[0][reg], huP = gP[1][reg], hvP = gP[2][reg], hNP = gP[3][reg];
+                    if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
+                    const double rM = crcp(hM), rP = crcp(hP);
+                    // the wave speeds use the exterior velocity BEFORE the wall condition (rhs.py:81-85, :93-94)
+                    const double uM = huM * rM, vM = hvM * rM, uP0 = huP * rP, vP0 = hvP * rP;
+                    const double spdM = csqrt(uM * uM + vM * vM) + csqrt(g * hM);
+                    const double spdP = csqrt(uP0 * uP0 + vP0 * vP0) + csqrt(g * hP);
+                    lam = valid ? fmax(lam, fmax(spdM, spdP)) : lam;
+                    if (wall) { // reflective wall (rhs.py:87-88)
+                        const double un = huM * nx + hvM * ny;
+                        huP = huM - 2 * nx * un;
+                        hvP = hvM - 2 * ny * un;
+                    }
+                    const double uP = huP * rP, vP = hvP * rP;
+                    const double prM = 0.5 * g * hM * hM, prP = 0.5 * g * hP * hP;
+                    const double F[4] = {huM + huP, (huM * uM + prM) + (huP * uP + prP), hvM * uM + hvP * uP, hNM * uM + hNP * uP};
+                    const double G[4] = {hvM + hvP, huM * vM + huP * vP, (hvM * vM + prM) + (hvP * vP + prP), hNM * vM + hNP * vP};
+                    const double dq[4] = {hM - hP, huM - huP, hvM - hvP, hNM - hNP};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        ef[b][reg][c] = hW * (F[c] * nx + G[c] * ny);
+                        dj[b][reg][c] = hW * dq[c];
+                    }
+                }
+            }
+            lam = fmax(lam, __shfl_xor(lam, 16)); // the face's Gauss points sit in the 4 lanes q of this element
+            lam = fmax(lam, __shfl_xor(lam, 32));
+#pragma unroll
+            for (int b = 0; b < FB; ++b)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    double sf[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sf[c] = fma(lam, dj[b][reg][c], ef[b][reg][c]);
+                    const int sbase = ldsSurf + (f * FB + b) * SCH + KV + KE;
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        const double a = L(sbase + r * 4 + reg);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sf[c], acc[c][r], 0, 0, 0);
+                    }
+                }
+        }
+
+        // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
+        const int slot = p.curvedSlot ? p.curvedSlot[k] : -1;
+        cmfma_t out[4][MT];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < MT; ++r) out[c][r] = cmfma_zero();
+        double S2[KV], S3[KV];
+#pragma unroll
+        for (int t = 0; t < KV; ++t) {
+            const int m = 4 * t + static_cast<int>(q);
+            const unsigned so = static_cast<unsigned>(4 * t) * ld8, vo = nodeOff(t);
+            const double rj = affTile ? (m < Np ? ea[13] : 0.0) : cbld_f64(rcoef, vo, so); // 0 on padding rows
+            {   // momentum sources at the node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx, S3 = -(f hu - CD |u| v) - g h zy
+                const double h = m < Np ? qB[0][t] : 1.0, hu = qB[1][t], hv = qB[2][t];
+                const double rh = crcp(h);
+                const double u = hu * rh, v = hv * rh;
+                const double fco = p.fcor ? cbld_f64(rcoef, vo, soFc + so) : p.fconst, cdv = p.cd ? cbld_f64(rcoef, vo, soCd + so) : p.cdconst;
+                const double cdn = cdv * csqrt(u * u + v * v);
+                const double zx = p.zx ? cbld_f64(rcoef, vo, soZx + so) : 0.0, zy = p.zy ? cbld_f64(rcoef, vo, soZy + so) : 0.0;
+                S2[t] = m < Np ? (fco * hv - cdn * u) - g * h * zx : 0.0;
+                S3[t] = m < Np ? -(fco * hu - cdn * v) - g * h * zy : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < MT; ++r) {
+                const double a = L(ldsMass + r * KV + t);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    out[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[c][t >> 2][t & 3] * rj, out[c][r], 0, 0, 0);
+                if constexpr (FILTER) {
+                    const double af = L(ldsF + r * KV + t);
+                    out[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S2[t], out[1][r], 0, 0, 0);
+                    out[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S3[t], out[2][r], 0, 0, 0);
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < KV; ++t) {
+                    const int m = 4 * t + static_cast<int>(q);
+                    if (m >= Np) continue;
+                    if (slot >= 0) { // element of curvedEls: its own mass matrix is applied by the fix-up kernel
+                        p.mmSide[(static_cast<long long>(c) * Np + m) * p.sideLd + slot] = acc[c][t >> 2][t & 3];
+                        continue;
+                    }
+                    double R = out[c][t >> 2][t & 3];
+                    if constexpr (!FILTER) R += c == 1 ? S2[t] : (c == 2 ? S3[t] : 0.0);
+                    const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
+                    if constexpr (MODE == CMODE_RHS) {
+                        cbst_f64(rout, v8, so, R);
+                    } else if constexpr (MODE == CMODE_LSERK) {
+                        const double n1 = p.ca * cbld_f64(rold, v8, so) + p.cc * R;
+                        cbst_f64(rold, v8, so, n1); // the residual, in place
+                        cbst_f64(rout, v8, so, qB[c][t] + p.cb * n1);
+                    } else {
+                        cbst_f64(rout, v8, so, p.ca * cbld_f64(rold, v8, so) + p.cb * qB[c][t] + p.cc * R);
+                    }
+                }
+        }
+    }
+}
+
+} // namespace bdg_dev

@@ -1,5 +1,6 @@
 // Instantiates the curved / over-integrated sw2d kernels for one polynomial order (-DBDG_ORDER=N).
 #include "sw2d_curved_kernel.hpp"
+#include "sw2d_curved_nt_kernel.hpp"
 #include <algorithm>
 #include <cstdlib>
 
@@ -108,7 +109,80 @@ hipError_t fixup(int mode, bool filter, const CurvedParams& p, hipStream_t strea
     }
 }
 
-const CurvedKernelTable kTable = {kN, O::Np, O::KV, O::MT, opsTiles, stageTiles, opsOffsets, gauss, stage, fixup};
+// ---- nodal-trace form (sw2d_curved_nt_kernel.hpp)
+using ONT = CurvedOpsNT<kN>;
+constexpr size_t kLdsLimitBytes = 160 * 1024;
+
+int ntTiles(int ncb, int fb) { return ONT::tiles(ncb, fb); }
+void ntOffsets(int ncb, int fb, int* off) {
+    off[0] = ONT::VCH; off[1] = ONT::SCH; off[2] = ONT::KE; off[3] = ONT::offSurf(ncb, 0); off[4] = ONT::offMass(ncb, fb);
+}
+size_t ntLdsResident(int ncb, int fb) { return (static_cast<size_t>(ONT::tiles(ncb, fb)) * 64 + 16 * ncb + 16 * fb) * sizeof(double); }
+size_t ntLdsStreamed(int ncb, int fb, bool filter) {
+    return (static_cast<size_t>(2 * ONT::VCH + 3 * fb * ONT::SCH + (filter ? 2 : 1) * ONT::MT * ONT::KV) * 64 + 16 * ncb + 16 * fb) * sizeof(double);
+}
+// Which forms are compiled for this order (compile time: every form is 24 kernels): the resident-image form up to order 6
+// (with the builders' default rules it fits there), the streamed form from order 5 on (BDG_SW2D_CURVED_STREAM=1 selects it
+// where both exist: A/B switch). An image that does not fit the form(s) of its order keeps the first kernels.
+constexpr bool kNtResident = BDG_ORDER <= 6, kNtStream = BDG_ORDER >= 5;
+bool ntStreamed(int ncb, int fb) {
+    static const bool force = [] { const char* e = std::getenv("BDG_SW2D_CURVED_STREAM"); return e && e[0] == '1'; }();
+    if (!kNtStream) return false;
+    return !kNtResident || force || ntLdsResident(ncb, fb) > static_cast<size_t>(kLdsBudgetBytes);
+}
+bool ntFits(int ncb, int fb, bool filter) {
+    if (fb < 1 || fb > 2) return false;
+    return ntStreamed(ncb, fb) ? ntLdsStreamed(ncb, fb, filter) <= kLdsLimitBytes
+                               : ntLdsResident(ncb, fb) <= static_cast<size_t>(kLdsBudgetBytes);
+}
+
+template <int MODE, bool FILTER, int STREAM, int FB, int WAVES>
+hipError_t launchNT(const CurvedParams& p, hipStream_t stream, size_t lds) {
+    auto kern = sw2d_curved_nt_kernel<kN, MODE, FILTER, STREAM, FB, WAVES>;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    // resident workgroups: WAVES per SIMD = WAVES workgroups of four waves per CU, as far as LDS allows
+    const int wgPerCu = std::max(1, std::min<int>(WAVES, static_cast<int>(kLdsLimitBytes / std::max<size_t>(lds, 1))));
+    const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u, wgs = (ntiles + 3u) / 4u;
+    const unsigned grid = std::max(1u, std::min(wgs, 256u * static_cast<unsigned>(wgPerCu) * (STREAM ? 1u : 2u)));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int MODE, bool FILTER>
+hipError_t launchStageNT(const CurvedParams& p, hipStream_t stream) {
+    if (p.K < 1) return hipSuccess;
+    const bool two = curvedWaves() == 2, streamed = ntStreamed(p.ncb, p.fb);
+    const size_t lds = streamed ? ntLdsStreamed(p.ncb, p.fb, FILTER) : ntLdsResident(p.ncb, p.fb);
+    if (lds > kLdsLimitBytes || p.fb < 1 || p.fb > 2) return hipErrorInvalidValue; // (ntFits was asked at creation)
+    if (streamed) {
+        if constexpr (kNtStream) {
+            if (p.fb == 1) return two ? launchNT<MODE, FILTER, 1, 1, 2>(p, stream, lds) : launchNT<MODE, FILTER, 1, 1, 1>(p, stream, lds);
+            return two ? launchNT<MODE, FILTER, 1, 2, 2>(p, stream, lds) : launchNT<MODE, FILTER, 1, 2, 1>(p, stream, lds);
+        }
+        return hipErrorInvalidValue;
+    }
+    if constexpr (kNtResident) {
+        if (p.fb == 1) return two ? launchNT<MODE, FILTER, 0, 1, 2>(p, stream, lds) : launchNT<MODE, FILTER, 0, 1, 1>(p, stream, lds);
+        return two ? launchNT<MODE, FILTER, 0, 2, 2>(p, stream, lds) : launchNT<MODE, FILTER, 0, 2, 1>(p, stream, lds);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t stageNT(int mode, bool filter, const CurvedParams& p, hipStream_t stream) {
+    switch (mode) {
+    case CMODE_RHS: return filter ? launchStageNT<CMODE_RHS, true>(p, stream) : launchStageNT<CMODE_RHS, false>(p, stream);
+    case CMODE_LSERK: return filter ? launchStageNT<CMODE_LSERK, true>(p, stream) : launchStageNT<CMODE_LSERK, false>(p, stream);
+    case CMODE_COMBINE: return filter ? launchStageNT<CMODE_COMBINE, true>(p, stream) : launchStageNT<CMODE_COMBINE, false>(p, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+const CurvedKernelTable kTable = {kN, O::Np, O::KV, O::MT, opsTiles, stageTiles, opsOffsets, gauss, stage, fixup,
+                                  ntTiles, ntOffsets, ntFits, stageNT};
 
 } // namespace
 

@@ -126,3 +126,4 @@ class Sw2dCurvedSolver:
 
     deviceBytes = property(lambda self: lib.bdg_sw2d_curved_device_bytes(self._h))
     bytesPerElement = property(lambda self: lib.bdg_sw2d_curved_bytes_per_element(self._h))
+    usesNodalTraces = property(lambda self: lib.bdg_sw2d_curved_form(self._h) == 1)

@@ -460,6 +460,11 @@ int bdg_sw2d_curved_synchronize(bdg_sw2d_curved* s);
 size_t bdg_sw2d_curved_device_bytes(const bdg_sw2d_curved* s);
 /* Compulsory HBM bytes of one RHS evaluation with the tables as this solver holds them (per element, averaged). */
 double bdg_sw2d_curved_bytes_per_element(const bdg_sw2d_curved* s);
+/* Which kernels serve this solver: 1 = the nodal-trace form (one stage launch per evaluation; the neighbours' Gauss traces
+ * are products of their face-node values: needs gmapM = identity, a gmapP that pairs whole faces and an Interp whose face
+ * rows vanish off the face nodes -- what buildGaussFaceNodes produces, periodic rewiring included), 0 = the general form
+ * (Gauss-trace planes; any map). Decided at creation; BDG_SW2D_CURVED_GENERAL=1 forces 0. -1: NULL handle. */
+int bdg_sw2d_curved_form(const bdg_sw2d_curved* s);
 
 #ifdef __cplusplus
 }

@@ -6,7 +6,8 @@ traffic derived as MI355X_MICROARCH.md prescribes: FETCH_SIZE/WRITE_SIZE are in 
 gfx950 FETCH_SIZE counts 64 B per 128-B request for coalesced streams, so reads = 2 x FETCH_SIZE
 -- calibrated here on scatter_rows_kernel<double>, whose byte count is known exactly).
 
-  python profiles/summarize.py <tag> <gpurun_out dir> [--into profiles/]
+  python profiles/summarize.py <tag> <gpurun_out dir> [--into profiles/] [--kernel sw2d_curved_stage]
+(--kernel: substring of the kernel the counters are summarized for; default the straight-element stage kernels)
 """
 import csv
 import glob
@@ -38,8 +39,9 @@ def counters(path, kernel_substr):
 
 def main():
     tag, out = sys.argv[1], sys.argv[2]
-    into = sys.argv[4] if len(sys.argv) > 4 and sys.argv[3] == "--into" else None
-    stage = "sw2d_stage"
+    opts = dict(zip(sys.argv[3::2], sys.argv[4::2]))
+    into = opts.get("--into")
+    stage = opts.get("--kernel", "sw2d_stage")
     summary = {"tag": tag, "kernel": None, "counters": {}, "launches_sampled": {}}
     # what the collection ran: bench.py only quotes a summary that matches its workload and the device sources of today
     try:
@@ -48,11 +50,13 @@ def main():
         summary["kernel_source_sha"] = bench.kernel_source_sha()
         for line in open(os.path.join(out, f"prof_{tag}_warm.log")):
             if line.startswith("{"):
-                cfg = json.loads(line)["config"]
+                d = json.loads(line)
+                cfg = d.get("config", d)        # bench.py nests them under "config", the profiles/time_*.py lines do not
                 summary["order"], summary["elements"] = cfg["order"], cfg["elements"]
+                summary["workload_line"] = {k: v for k, v in d.items() if k not in ("config", "roofline", "cpu_baseline")}
     except Exception as e:  # noqa: BLE001  (a summary without the tie is still a summary; bench.py then ignores it)
         summary["kernel_source_sha_error"] = repr(e)
-    for group in ("fetch", "write", "tcc", "sq", "grbm", "mfma"):
+    for group in ("fetch", "write", "tcc", "sq", "grbm", "mfma", "mem"):
         vals, n, extra = counters(os.path.join(out, f"prof_{tag}_{group}"), stage)
         summary["counters"].update(vals)
         summary["launches_sampled"].update(n)

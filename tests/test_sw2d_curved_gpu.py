@@ -42,15 +42,27 @@ def solver_from_fixture(d):
                             zx=d["zx"], zy=d["zy"], f=float(d["f"]), CD=d["CD"])
 
 
+@pytest.fixture(params=["nodal-trace", "general"], autouse=True)
+def form(request, monkeypatch):
+    """Every test of this file runs on both kernel forms: the default nodal-trace form (one launch, the neighbours' traces
+    are products of their face-node values) and the general form with Gauss-trace planes (BDG_SW2D_CURVED_GENERAL=1)."""
+    if request.param == "general":
+        monkeypatch.setenv("BDG_SW2D_CURVED_GENERAL", "1")
+    else:
+        monkeypatch.delenv("BDG_SW2D_CURVED_GENERAL", raising=False)
+    return request.param
+
+
 def relerr(got, ref):
     scale = max(np.abs(r).max() for r in ref)
     return max(np.abs(a - b).max() for a, b in zip(got, ref)) / scale
 
 
 @pytest.mark.parametrize("path", CURVED, ids=IDS)
-def test_curved_rhs_matches_the_reference_function(path):
+def test_curved_rhs_matches_the_reference_function(path, form):
     d = np.load(path)
     s = solver_from_fixture(d)
+    assert s.usesNodalTraces == (form == "nodal-trace")          # every fixture (the periodic one too) has the structure
     ref = [d[f"rhs{i}"] for i in (1, 2, 3, 4)]
     got = s.computeRHS(d["h"], d["hu"], d["hv"], d["hN"])
     assert relerr(got, ref) < RHS_TOL
@@ -180,6 +192,31 @@ def test_straight_mesh_without_curved_elements_and_constant_sources():
     assert relerr(s.computeRHS(h, hu, hv, hN), ref) < RHS_TOL
     with pytest.raises(BdgError, match="Filter"):
         s.computeRHS(h, hu, hv, hN, filter=True)                 # ctx.filter was never built
+
+
+def test_contexts_without_face_structure_fall_back_to_the_general_form(form):
+    """The nodal-trace form needs gmapM = identity and a gmapP that pairs whole faces; anything else must be served by
+    the general form, with the same answer as the oracle (which follows whatever maps it is given)."""
+    from oracle import oracle_np
+    d = dict(np.load(os.path.join(GOLDEN, "sw2d_rhs_curved_coarse_box_N3.npz")))
+    NG = int(d["NGauss"])
+    # (i) two Gauss points of one interior face exchange their partners: the face is no longer paired as a whole
+    gmapP = d["gmapP"].copy()
+    inner = np.where(gmapP != np.arange(gmapP.size))[0]
+    i0 = int(inner[0]) // NG * NG
+    gmapP[i0], gmapP[i0 + 1] = gmapP[i0 + 1], gmapP[i0]
+    # (ii) an interior-side map that is not the identity
+    gmapM = d["gmapM"].copy()
+    gmapM[i0 + 2], gmapM[i0 + 3] = gmapM[i0 + 3], gmapM[i0 + 2]
+    for maps in (dict(gmapP=gmapP), dict(gmapM=gmapM)):
+        t = dict(d, **maps)
+        ctx, cub, gauss = contexts_from_fixture(t)
+        s = Sw2dCurvedSolver(ctx, cub, gauss, t["curvedEls"], t["J"], t["gmapM"], t["gmapP"], g=float(t["g"]), zx=t["zx"],
+                             zy=t["zy"], f=float(t["f"]), CD=t["CD"])
+        assert not s.usesNodalTraces
+        ref = oracle_np.sw2d_rhs_curved(t["h"], t["hu"], t["hv"], t["hN"], t["zx"], t["zy"], float(t["g"]), float(t["f"]), t["CD"], t)
+        assert relerr(s.computeRHS(t["h"], t["hu"], t["hv"], t["hN"]), ref) < RHS_TOL
+        assert relerr(ref, [d[f"rhs{i}"] for i in (1, 2, 3, 4)]) > 1e-6      # the rewiring does change the answer
 
 
 def test_bad_tables_are_refused_before_anything_runs():
