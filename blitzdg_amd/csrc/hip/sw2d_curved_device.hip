@@ -89,7 +89,7 @@ struct bdg_sw2d_curved {
     // nodal-trace form (sw2d_curved_nt_kernel.hpp): used when the context has the structure it needs (useNT)
     bool useNT = false;
     Buf<double> opsNT, elAffine, gaussWref;
-    Buf<int> nodeP, faceFlags, affineNT;
+    Buf<int> nodeP, faceFlags;
     int numAffineNT = 0;
     double g = 9.81, fconst = 0.0, cdconst = 0.0;
     long long stageCount = 0;
@@ -127,7 +127,7 @@ struct bdg_sw2d_curved {
         p.ops = ops.p; p.filt = filt.p; p.ld = ld; p.K = K; p.ncb = ncb; p.ncub = ncub; p.ng = ng; p.fb = fb; p.g = g;
         if (useNT) {
             p.opsNT = opsNT.p; p.nodeP = nodeP.p; p.faceFlags = faceFlags.p; p.gaussWref = gaussWref.p;
-            p.affineEl = numAffineNT ? affineNT.p : nullptr; p.elAffine = numAffineNT ? elAffine.p : nullptr;
+            p.affineEl = nullptr; p.elAffine = elAffine.p; // (the straight-element flag rides in faceFlags)
         }
         return p;
     }
@@ -266,7 +266,6 @@ void buildNodalTraceTables(bdg_sw2d_curved& s, const bdg_sw2d_curved_desc& d, co
                     i < Nfp ? static_cast<int>(faceNodes[f2][pm[i]] * ld + k2) : k; // padding rows: an own node (the column of GE is zero)
         }
     if (!structured) return;
-    for (long long k = K; k < ld; ++k) flags[k] = flags[K - 1];
 
     hipStream_t st = s.stream;
     // ---- straight-sided elements: the cubature numbers of the first form's test, the Gauss geometry and the nodal Jacobian
@@ -331,9 +330,8 @@ void buildNodalTraceTables(bdg_sw2d_curved& s, const bdg_sw2d_curved_desc& d, co
         }
     }
     s.numAffineNT = count;
-    for (long long k = K; k < ld; ++k) aff[k] = aff[K - 1];
-    s.affineNT.alloc(static_cast<size_t>(ld), s.bytes, st);
-    hipOk(hipMemcpyAsync(s.affineNT.p, aff.data(), aff.size() * sizeof(int), hipMemcpyHostToDevice, st), "affine flags upload");
+    for (int k = 0; k < K; ++k) flags[k] |= aff[k] ? 8 : 0;          // bit 3: straight element (bits 0..2: wall faces)
+    for (long long k = K; k < ld; ++k) flags[k] = flags[K - 1];       // padding lanes repeat the last element
     s.elAffine.alloc(static_cast<size_t>(14) * ld, s.bytes, st);
     s.uploadRows(ea.data(), s.elAffine.p, 14);
     if (!s.cubWref.p) { // (the first form's reference weights when it found straight elements: the same numbers)

@@ -72,8 +72,8 @@ struct CurvedParams {
     // nodal-trace form (sw2d_curved_nt_kernel.hpp); nullptr / unused in the first form
     const double* opsNT;     // operator image in CurvedOpsNT layout
     const int* nodeP;        // (3 * KE * 4, ld): offset row * ld + k of the neighbour's node at my face node (face f, node i) at row f * KE * 4 + i
-    const int* faceFlags;    // ld: bit f set = face f is a wall
-    const double* elAffine;  // (14, ld): straight elements: W rx, W ry, W sx, W sy factors; nx, ny, W factor per face; 1 / J
+    const int* faceFlags;    // ld: bit f set = face f is a wall; bit 3: straight element (elAffine holds its numbers)
+    const double* elAffine;  // (14, ld), zeros on other elements: straight elements: W rx, W ry, W sx, W sy factors; nx, ny, W factor per face; 1 / J
     const double* gaussWref; // 16 fb: HALF the Gauss weights of a reference straight face (zero padded)
     const double* filt;   // (Np, Np) row-major filter for the fix-up kernel, or nullptr
     long long ld;

@@ -25,6 +25,7 @@
 // Layout of lanes, operands and accumulators: as described at the top of sw2d_curved_kernel.hpp.
 #pragma once
 #include "sw2d_curved_kernel.hpp"
+#include <type_traits>
 
 namespace bdg_dev {
 
@@ -55,7 +56,9 @@ struct CurvedOpsNT {
 
 // STREAM = 0: whole image resident in LDS. STREAM = 1: volume chunks through a double buffer, the workgroup's waves in
 // lockstep; resident: surface blocks, the mass tiles this launch uses (M or MF, and F when FILTER).
-template <int N, int MODE, bool FILTER, int STREAM, int FB, int WAVES>
+// RL: 4-row steps of a face's LAST 16-row block that hold Gauss points (ceil((NG - 16 (FB - 1)) / 4)): the pointwise work
+// and the lift products of the steps beyond are skipped (NG = 10: 3 of 4 steps; NG = 18: 1 of 4 in the second block).
+template <int N, int MODE, bool FILTER, int STREAM, int FB, int WAVES, int RL = 4>
 __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const CurvedParams p) {
     using O = CurvedOpsNT<N>;
     constexpr int Np = O::Np, KV = O::KV, MT = O::MT, KE = O::KE, VCH = O::VCH, SCH = O::SCH;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
     const __amdgpu_buffer_rsrc_t rcub = cplane_rsrc(p.cubG, 4u * cplaneB); // read on curved / mixed tiles only (< 4 GiB: checked at creation)
     const __amdgpu_buffer_rsrc_t rnodeP = cplane_rsrc(p.nodeP, static_cast<unsigned>(3 * KE * 4) * ld4),
                                  rcoef = cplane_rsrc(p.rJ, ncoef * planeB), // rJ [, zx, zy, fcor, cd]: planes of ONE allocation
-                                 raff = cplane_rsrc(p.elAffine ? p.elAffine : p.rJ, 14u * ld8);
+                                 raff = cplane_rsrc(p.elAffine, 14u * ld8);
     const unsigned soZx = p.zx ? static_cast<unsigned>((p.zx - p.rJ) * 8) : 0u, soZy = p.zy ? static_cast<unsigned>((p.zy - p.rJ) * 8) : 0u,
                    soFc = p.fcor ? static_cast<unsigned>((p.fcor - p.rJ) * 8) : 0u, soCd = p.cd ? static_cast<unsigned>((p.cd - p.rJ) * 8) : 0u;
     const double g = p.g;
@@ -142,261 +145,336 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
             return v8;
         };
 
-        // ---- own nodal state in operand layout: node m = 4 t + q (0 on padding rows)
+        // ---- requests of the tile's first round trip, all in flight together: own nodal state in operand layout (node
+        //      m = 4 t + q, 0 on padding rows), the straight-element numbers (zeros on other elements: read unconditionally, so
+        //      that they do not wait for the flag), the flags (bits 0..2: wall faces, bit 3: straight element), and the
+        //      neighbours' nodes at my face nodes (face node i = 4 t2 + q of face f; rows beyond Nfp point at an own node, the
+        //      matching column of GE is zero)
         double qB[4][KV];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
             for (int t = 0; t < KV; ++t) qB[c][t] = cbld_f64(rq, nodeOff(t), static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8);
-        // straight-sided tile? (one ballot; padding lanes repeat the last element)
-        bool affTile = false;
-        double ea[14];
-#pragma unroll
-        for (int i = 0; i < 14; ++i) ea[i] = 0.0;
-        if (p.elAffine) {
-            affTile = __all(p.affineEl[k] != 0);
-            if (affTile) {
-#pragma unroll
-                for (int i = 0; i < 14; ++i) ea[i] = cbld_f64(raff, k8, static_cast<unsigned>(i) * ld8);
-            }
-        }
-        const int wallBits = p.faceFlags[k];
-        // the neighbours' nodes at my face nodes: face node i = 4 t2 + q of face f (rows beyond Nfp point at an own node:
-        // the matching column of GE is zero)
+        const int flags = p.faceFlags[k];
         int idxP[3][KE];
 #pragma unroll
         for (int f = 0; f < 3; ++f)
 #pragma unroll
             for (int t2 = 0; t2 < KE; ++t2) idxP[f][t2] = cbld_i32(rnodeP, v4, static_cast<unsigned>(f * KE * 4 + 4 * t2) * ld4);
+        double ea[5]; // W rx, W ry, W sx, W sy factors and 1 / J of a straight element (the faces' numbers ride with their gathers)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ea[i] = cbld_f64(raff, k8, static_cast<unsigned>(i) * ld8);
+        ea[4] = cbld_f64(raff, k8, 13u * ld8);
+        __builtin_amdgcn_sched_barrier(0);
+        const bool affTile = __all((flags & 8) != 0); // straight-sided tile? (padding lanes repeat the last element)
 
-        cmfma_t acc[4][MT];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < MT; ++r) acc[c][r] = cmfma_zero();
-
-        // ---- volume term, 16 cubature points at a time
-        for (int rb = 0; rb < ncb; ++rb) {
-            int base; // LDS tile index of this chunk
-            f64x2 pre[(VCH * 32 + 255) / 256];
-            if constexpr (STREAM) {
-                base = phase * VCH;
-                // request the next chunk (this tile's rb + 1, or chunk 0 for the next pass) before the products
-                const int nextRb = rb + 1 < ncb ? rb + 1 : 0;
-                const f64x2* __restrict__ s2 = reinterpret_cast<const f64x2*>(p.opsNT + static_cast<size_t>(O::offVol(nextRb)) * 64);
-#pragma unroll
-                for (int i = 0; i < (VCH * 32 + 255) / 256; ++i) {
-                    const int at = static_cast<int>(threadIdx.x) + i * 256;
-                    if (at < VCH * 32) pre[i] = s2[at];
-                }
-            } else {
-                base = O::offVol(rb);
-            }
-            if (act) {
-                cmfma_t cv[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) cv[c] = cmfma_zero();
-#pragma unroll
-                for (int t = 0; t < KV; ++t) {
-                    const double a = L(base + t);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) cv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], cv[c], 0, 0, 0);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) { // 4 cubature points of this lane = contraction step reg of DrT / DsT
-                    const int row = 16 * rb + static_cast<int>(q) + 4 * reg;
-                    const unsigned so = static_cast<unsigned>(16 * rb + 4 * reg) * ld8;
-                    double wrx, wry, wsx, wsy;
-                    if (affTile) { // rule weight (times a reference Jacobian) of this point, the element's four numbers
-                        const double w = sOps[wrefAt + row]; // zero on padding rows
-                        wrx = w * ea[0]; wry = w * ea[1]; wsx = w * ea[2]; wsy = w * ea[3];
-                    } else {
-                        wrx = cbld_f64(rcub, v8, so); wry = cbld_f64(rcub, v8, cplaneB + so);
-                        wsx = cbld_f64(rcub, v8, 2u * cplaneB + so); wsy = cbld_f64(rcub, v8, 3u * cplaneB + so);
-                    }
-                    const bool valid = row < p.ncub;
-                    const CurvedFlux fl = curved_fluxes(valid ? cv[0][reg] : 1.0, cv[1][reg], cv[2][reg], cv[3][reg], g);
-                    double tr[4], ts[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        tr[c] = wrx * fl.F[c] + wry * fl.G[c];
-                        ts[c] = wsx * fl.F[c] + wsy * fl.G[c];
-                    }
-#pragma unroll
-                    for (int r = 0; r < MT; ++r) {
-                        const double aDr = L(base + KV + r * 4 + reg), aDs = L(base + KV + 4 * MT + r * 4 + reg);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDr, tr[c], acc[c][r], 0, 0, 0);
-                            acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDs, ts[c], acc[c][r], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-            if constexpr (STREAM) {
-                f64x2* __restrict__ d2 = reinterpret_cast<f64x2*>(sOps + static_cast<size_t>((phase ^ 1) * VCH) * 64);
-#pragma unroll
-                for (int i = 0; i < (VCH * 32 + 255) / 256; ++i) {
-                    const int at = static_cast<int>(threadIdx.x) + i * 256;
-                    if (at < VCH * 32) d2[at] = pre[i];
-                }
-                __syncthreads();
-                phase ^= 1;
-            }
-        }
-        if (!act) continue; // (lockstep form: nothing but barriers above for a wave without a tile)
-
-        // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            // the neighbour's values at my face nodes (operand layout of GE: face node 4 t2 + q)
-            double qP[4][KE];
+        // the neighbour's values at my face nodes (operand layout of GE) and, for a straight element, the face's nx, ny, W factor
+        auto gather = [&](int f, double (&qP)[4][KE], double (&fa)[3]) {
 #pragma unroll
             for (int t2 = 0; t2 < KE; ++t2) {
                 const unsigned oP = static_cast<unsigned>(idxP[f][t2]) * 8u;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) qP[c][t2] = cbld_f64(rq, oP, static_cast<unsigned>(c) * planeB);
             }
-            const bool wall = (wallBits >> f) & 1;
-            double lam = 0.0;
-            double ef[FB][4][4], dj[FB][4][4];
 #pragma unroll
-            for (int b = 0; b < FB; ++b) {
-                const int gb = f * FB + b, sbase = ldsSurf + gb * SCH;
-                cmfma_t gM[4], gP[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { gM[c] = cmfma_zero(); gP[c] = cmfma_zero(); }
-#pragma unroll
-                for (int t = 0; t < KV; ++t) {
-                    const double a = L(sbase + t);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], gM[c], 0, 0, 0);
-                }
-#pragma unroll
-                for (int t2 = 0; t2 < KE; ++t2) {
-                    const double a = L(sbase + KV + t2);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) gP[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qP[c][t2], gP[c], 0, 0, 0);
-                }
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int local = 16 * b + static_cast<int>(q) + 4 * reg;
-                    const bool valid = local < p.ng;
-                    double nx, ny, hW;
-                    if (affTile) {
-                        nx = ea[4 + 3 * f]; ny = ea[5 + 3 * f];
-                        hW = sOps[gwrefAt + local] * ea[6 + 3 * f]; // gwref holds half the reference weights; zero on padding rows
-                    } else {
-                        const unsigned so8 = static_cast<unsigned>(16 * gb + 4 * reg) * ld8;
-                        nx = cbld_f64(rgg, v8, so8); ny = cbld_f64(rgg, v8, gplaneB + so8);
-                        hW = 0.5 * cbld_f64(rgg, v8, 2u * gplaneB + so8); // zero on padding rows
-                    }
-                    double hM = gM[0][reg], huM = gM[1][reg], hvM = gM[2][reg], hNM = gM[3][reg];
-                    double hP = gP[0][reg], huP = gP[1][reg], hvP = gP[2][reg], hNP = gP[3][reg];
-                    if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
-                    const double rM = crcp(hM), rP = crcp(hP);
-                    // the wave speeds use the exterior velocity BEFORE the wall condition (rhs.py:81-85, :93-94)
-                    const double uM = huM * rM, vM = hvM * rM, uP0 = huP * rP, vP0 = hvP * rP;
-                    const double spdM = csqrt(uM * uM + vM * vM) + csqrt(g * hM);
-                    const double spdP = csqrt(uP0 * uP0 + vP0 * vP0) + csqrt(g * hP);
-                    lam = valid ? fmax(lam, fmax(spdM, spdP)) : lam;
-                    if (wall) { // reflective wall (rhs.py:87-88)
-                        const double un = huM * nx + hvM * ny;
-                        huP = huM - 2 * nx * un;
-                        hvP = hvM - 2 * ny * un;
-                    }
-                    const double uP = huP * rP, vP = hvP * rP;
-                    const double prM = 0.5 * g * hM * hM, prP = 0.5 * g * hP * hP;
-                    const double F[4] = {huM + huP, (huM * uM + prM) + (huP * uP + prP), hvM * uM + hvP * uP, hNM * uM + hNP * uP};
-                    const double G[4] = {hvM + hvP, huM * vM + huP * vP, (hvM * vM + prM) + (hvP * vP + prP), hNM * vM + hNP * vP};
-                    const double dq[4] = {hM - hP, huM - huP, hvM - hvP, hNM - hNP};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        ef[b][reg][c] = hW * (F[c] * nx + G[c] * ny);
-                        dj[b][reg][c] = hW * dq[c];
-                    }
-                }
-            }
-            lam = fmax(lam, __shfl_xor(lam, 16)); // the face's Gauss points sit in the 4 lanes q of this element
-            lam = fmax(lam, __shfl_xor(lam, 32));
-#pragma unroll
-            for (int b = 0; b < FB; ++b)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    double sf[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) sf[c] = fma(lam, dj[b][reg][c], ef[b][reg][c]);
-                    const int sbase = ldsSurf + (f * FB + b) * SCH + KV + KE;
-#pragma unroll
-                    for (int r = 0; r < MT; ++r) {
-                        const double a = L(sbase + r * 4 + reg);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sf[c], acc[c][r], 0, 0, 0);
-                    }
-                }
-        }
+            for (int i = 0; i < 3; ++i) fa[i] = cbld_f64(raff, k8, static_cast<unsigned>(4 + 3 * f + i) * ld8);
+        };
 
-        // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
-        const int slot = p.curvedSlot ? p.curvedSlot[k] : -1;
-        cmfma_t out[4][MT];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int r = 0; r < MT; ++r) out[c][r] = cmfma_zero();
-        double S2[KV], S3[KV];
-#pragma unroll
-        for (int t = 0; t < KV; ++t) {
-            const int m = 4 * t + static_cast<int>(q);
-            const unsigned so = static_cast<unsigned>(4 * t) * ld8, vo = nodeOff(t);
-            const double rj = affTile ? (m < Np ? ea[13] : 0.0) : cbld_f64(rcoef, vo, so); // 0 on padding rows
-            {   // momentum sources at the node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx, S3 = -(f hu - CD |u| v) - g h zy
-                const double h = m < Np ? qB[0][t] : 1.0, hu = qB[1][t], hv = qB[2][t];
-                const double rh = crcp(h);
-                const double u = hu * rh, v = hv * rh;
-                const double fco = p.fcor ? cbld_f64(rcoef, vo, soFc + so) : p.fconst, cdv = p.cd ? cbld_f64(rcoef, vo, soCd + so) : p.cdconst;
-                const double cdn = cdv * csqrt(u * u + v * v);
-                const double zx = p.zx ? cbld_f64(rcoef, vo, soZx + so) : 0.0, zy = p.zy ? cbld_f64(rcoef, vo, soZy + so) : 0.0;
-                S2[t] = m < Np ? (fco * hv - cdn * u) - g * h * zx : 0.0;
-                S3[t] = m < Np ? -(fco * hu - cdn * v) - g * h * zy : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < MT; ++r) {
-                const double a = L(ldsMass + r * KV + t);
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    out[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[c][t >> 2][t & 3] * rj, out[c][r], 0, 0, 0);
-                if constexpr (FILTER) {
-                    const double af = L(ldsF + r * KV + t);
-                    out[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S2[t], out[1][r], 0, 0, 0);
-                    out[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S3[t], out[2][r], 0, 0, 0);
-                }
-            }
-        }
-        if (live) {
+        // The tile's work, compiled twice: AFF = every element of the tile is straight-sided (geometry from the 14 numbers and
+        // the reference weights in LDS) or not (geometry from the planes). One wave-uniform branch per tile instead of one per
+        // cubature row / Gauss row / node: the bodies of the loops below are single basic blocks the scheduler can work in.
+        auto body = [&](auto affC) {
+            constexpr bool AFF = decltype(affC)::value;
+            double qP[4][KE], fa[3];
+            gather(0, qP, fa); // face 0's exterior nodes: the volume term hides their round trip
+            __builtin_amdgcn_sched_barrier(0);
+
+            cmfma_t acc[4][MT];
 #pragma unroll
             for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < MT; ++r) acc[c][r] = cmfma_zero();
+
+            // ---- volume term, 16 cubature points at a time
+            for (int rb = 0; rb < ncb; ++rb) {
+                int base; // LDS tile index of this chunk
+                f64x2 pre[(VCH * 32 + 255) / 256];
+                if constexpr (STREAM) {
+                    base = phase * VCH;
+                    // request the next chunk (this tile's rb + 1, or chunk 0 for the next pass) before the products
+                    const int nextRb = rb + 1 < ncb ? rb + 1 : 0;
+                    const f64x2* __restrict__ s2 = reinterpret_cast<const f64x2*>(p.opsNT + static_cast<size_t>(O::offVol(nextRb)) * 64);
+#pragma unroll
+                    for (int i = 0; i < (VCH * 32 + 255) / 256; ++i) {
+                        const int at = static_cast<int>(threadIdx.x) + i * 256;
+                        if (at < VCH * 32) pre[i] = s2[at];
+                    }
+                } else {
+                    base = O::offVol(rb);
+                }
+                if (act) {
+                    cmfma_t cv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) cv[c] = cmfma_zero();
+#pragma unroll
+                    for (int t = 0; t < KV; ++t) {
+                        const double a = L(base + t);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) cv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], cv[c], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) { // 4 cubature points of this lane = contraction step reg of DrT / DsT
+                        const int row = 16 * rb + static_cast<int>(q) + 4 * reg;
+                        const unsigned so = static_cast<unsigned>(16 * rb + 4 * reg) * ld8;
+                        double wrx, wry, wsx, wsy;
+                        if constexpr (AFF) { // rule weight (times a reference Jacobian) of this point, the element's four numbers
+                            const double w = sOps[wrefAt + row]; // zero on padding rows
+                            wrx = w * ea[0]; wry = w * ea[1]; wsx = w * ea[2]; wsy = w * ea[3];
+                        } else {
+                            wrx = cbld_f64(rcub, v8, so); wry = cbld_f64(rcub, v8, cplaneB + so);
+                            wsx = cbld_f64(rcub, v8, 2u * cplaneB + so); wsy = cbld_f64(rcub, v8, 3u * cplaneB + so);
+                        }
+                        const bool valid = row < p.ncub;
+                        const CurvedFlux fl = curved_fluxes(valid ? cv[0][reg] : 1.0, cv[1][reg], cv[2][reg], cv[3][reg], g);
+                        double tr[4], ts[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            tr[c] = wrx * fl.F[c] + wry * fl.G[c];
+                            ts[c] = wsx * fl.F[c] + wsy * fl.G[c];
+                        }
+#pragma unroll
+                        for (int r = 0; r < MT; ++r) {
+                            const double aDr = L(base + KV + r * 4 + reg), aDs = L(base + KV + 4 * MT + r * 4 + reg);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDr, tr[c], acc[c][r], 0, 0, 0);
+                                acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDs, ts[c], acc[c][r], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+                if constexpr (STREAM) {
+                    f64x2* __restrict__ d2 = reinterpret_cast<f64x2*>(sOps + static_cast<size_t>((phase ^ 1) * VCH) * 64);
+#pragma unroll
+                    for (int i = 0; i < (VCH * 32 + 255) / 256; ++i) {
+                        const int at = static_cast<int>(threadIdx.x) + i * 256;
+                        if (at < VCH * 32) d2[at] = pre[i];
+                    }
+                    __syncthreads();
+                    phase ^= 1;
+                }
+            }
+            if (!act) return; // (lockstep form: nothing but barriers above for a wave without a tile)
+
+            // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const bool wall = (flags >> f) & 1;
+                const double fnx = fa[0], fny = fa[1], fw = fa[2];
+                cmfma_t gP[FB][4];
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const int sbase = ldsSurf + (f * FB + b) * SCH;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) gP[b][c] = cmfma_zero();
+#pragma unroll
+                    for (int t2 = 0; t2 < KE; ++t2) {
+                        const double a = L(sbase + KV + t2);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) gP[b][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qP[c][t2], gP[b][c], 0, 0, 0);
+                    }
+                }
+                if (f < 2) gather(f + 1, qP, fa); // the next face's nodes while this face is worked on (qP's products are issued)
+                __builtin_amdgcn_sched_barrier(0);
+                double lam = 0.0;
+                double ef[FB][4][4], dj[FB][4][4];
+#pragma unroll
+                for (int b = 0; b < FB; ++b) {
+                    const int gb = f * FB + b;
+                    cmfma_t gM[4]; // the element's own traces at this block's 16 Gauss rows
+                    {
+                        const int sbase = ldsSurf + gb * SCH;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) gM[c] = cmfma_zero();
+#pragma unroll
+                        for (int t = 0; t < KV; ++t) {
+                            const double a = L(sbase + t);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], gM[c], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < (b == FB - 1 ? RL : 4); ++reg) {
+                        const int local = 16 * b + static_cast<int>(q) + 4 * reg;
+                        const bool valid = local < p.ng;
+                        double nx, ny, hW;
+                        if constexpr (AFF) {
+                            nx = fnx; ny = fny;
+                            hW = sOps[gwrefAt + local] * fw; // gwref holds half the reference weights; zero on padding rows
+                        } else {
+                            const unsigned so8 = static_cast<unsigned>(16 * gb + 4 * reg) * ld8;
+                            nx = cbld_f64(rgg, v8, so8); ny = cbld_f64(rgg, v8, gplaneB + so8);
+                            hW = 0.5 * cbld_f64(rgg, v8, 2u * gplaneB + so8); // zero on padding rows
+                        }
+                        double hM = gM[0][reg], huM = gM[1][reg], hvM = gM[2][reg], hNM = gM[3][reg];
+                        double hP = gP[b][0][reg], huP = gP[b][1][reg], hvP = gP[b][2][reg], hNP = gP[b][3][reg];
+                        if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
+                        const double rM = crcp(hM), rP = crcp(hP);
+                        // the wave speeds use the exterior velocity BEFORE the wall condition (rhs.py:81-85, :93-94)
+                        const double uM = huM * rM, vM = hvM * rM, uP0 = huP * rP, vP0 = hvP * rP;
+                        const double spdM = csqrt(uM * uM + vM * vM) + csqrt(g * hM);
+                        const double spdP = csqrt(uP0 * uP0 + vP0 * vP0) + csqrt(g * hP);
+                        lam = valid ? fmax(lam, fmax(spdM, spdP)) : lam;
+                        if (wall) { // reflective wall (rhs.py:87-88)
+                            const double un = huM * nx + hvM * ny;
+                            huP = huM - 2 * nx * un;
+                            hvP = hvM - 2 * ny * un;
+                        }
+                        const double uP = huP * rP, vP = hvP * rP;
+                        const double prM = 0.5 * g * hM * hM, prP = 0.5 * g * hP * hP;
+                        const double F[4] = {huM + huP, (huM * uM + prM) + (huP * uP + prP), hvM * uM + hvP * uP, hNM * uM + hNP * uP};
+                        const double G[4] = {hvM + hvP, huM * vM + huP * vP, (hvM * vM + prM) + (hvP * vP + prP), hNM * vM + hNP * vP};
+                        const double dq[4] = {hM - hP, huM - huP, hvM - hvP, hNM - hNP};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            ef[b][reg][c] = hW * (F[c] * nx + G[c] * ny);
+                            dj[b][reg][c] = hW * dq[c];
+                        }
+                    }
+                }
+                lam = fmax(lam, __shfl_xor(lam, 16)); // the face's Gauss points sit in the 4 lanes q of this element
+                lam = fmax(lam, __shfl_xor(lam, 32));
+#pragma unroll
+                for (int b = 0; b < FB; ++b)
+#pragma unroll
+                    for (int reg = 0; reg < (b == FB - 1 ? RL : 4); ++reg) {
+                        double sf[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sf[c] = fma(lam, dj[b][reg][c], ef[b][reg][c]);
+                        const int sbase = ldsSurf + (f * FB + b) * SCH + KV + KE;
+#pragma unroll
+                        for (int r = 0; r < MT; ++r) {
+                            const double a = L(sbase + r * 4 + reg);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sf[c], acc[c][r], 0, 0, 0);
+                        }
+                    }
+            }
+
+            // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
+            const int slot = p.curvedSlot ? p.curvedSlot[k] : -1;
+            cmfma_t out[4][MT];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int r = 0; r < MT; ++r) out[c][r] = cmfma_zero();
+            // Rows of this phase -- the source tables, 1 / J on general tiles, the residual / base state of the update -- are
+            // requested TC k-steps (one field) ahead of their use: everything at once is 17 rows per k-step, 400 registers at N = 8.
+            constexpr int TC = KV < 4 ? KV : 4, NCH = (KV + TC - 1) / TC;
+            struct Rows { double cf[TC], cd[TC], zx[TC], zy[TC], rj[TC]; };
+            auto requestRows = [&](int ch, Rows& w) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int t = ch * TC + i;
+                    if (t >= KV) break;
+                    const unsigned so = static_cast<unsigned>(4 * t) * ld8, vo = nodeOff(t);
+                    if constexpr (!AFF) w.rj[i] = cbld_f64(rcoef, vo, so); // 0 on padding rows
+                    w.cf[i] = p.fcor ? cbld_f64(rcoef, vo, soFc + so) : p.fconst;
+                    w.cd[i] = p.cd ? cbld_f64(rcoef, vo, soCd + so) : p.cdconst;
+                    w.zx[i] = p.zx ? cbld_f64(rcoef, vo, soZx + so) : 0.0;
+                    w.zy[i] = p.zy ? cbld_f64(rcoef, vo, soZy + so) : 0.0;
+                }
+            };
+            auto requestOld = [&](int c, double (&o)[KV]) {
+                if constexpr (MODE != CMODE_RHS) {
+#pragma unroll
+                    for (int t = 0; t < KV; ++t) o[t] = cbld_f64(rold, v8, static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8);
+                }
+            };
+            Rows rows[2];
+            requestRows(0, rows[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            double S2[KV], S3[KV];
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                if (ch + 1 < NCH) requestRows(ch + 1, rows[(ch + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const Rows& w = rows[ch & 1];
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int t = ch * TC + i;
+                    if (t >= KV) break;
+                    const int m = 4 * t + static_cast<int>(q);
+                    const double rj = AFF ? (m < Np ? ea[4] : 0.0) : w.rj[i];
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) {
+                        const double a = L(ldsMass + r * KV + t);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            out[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[c][t >> 2][t & 3] * rj, out[c][r], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int t = ch * TC + i;
+                    if (t >= KV) break;
+                    const int m = 4 * t + static_cast<int>(q);
+                    {   // momentum sources at the node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx, S3 = -(f hu - CD |u| v) - g h zy
+                        const double h = m < Np ? qB[0][t] : 1.0, hu = qB[1][t], hv = qB[2][t];
+                        const double rh = crcp(h);
+                        const double u = hu * rh, v = hv * rh;
+                        const double cdn = w.cd[i] * csqrt(u * u + v * v);
+                        S2[t] = m < Np ? (w.cf[i] * hv - cdn * u) - g * h * w.zx[i] : 0.0;
+                        S3[t] = m < Np ? -(w.cf[i] * hu - cdn * v) - g * h * w.zy[i] : 0.0;
+                    }
+                    if constexpr (FILTER) {
+#pragma unroll
+                        for (int r = 0; r < MT; ++r) {
+                            const double af = L(ldsF + r * KV + t);
+                            out[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S2[t], out[1][r], 0, 0, 0);
+                            out[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S3[t], out[2][r], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            if (live && slot >= 0) { // element of curvedEls: its own mass matrix is applied by the fix-up kernel
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int t = 0; t < KV; ++t) {
+                        const int m = 4 * t + static_cast<int>(q);
+                        if (m < Np) p.mmSide[(static_cast<long long>(c) * Np + m) * p.sideLd + slot] = acc[c][t >> 2][t & 3];
+                    }
+            }
+            const bool store = live && slot < 0;
+            double oldv[2][KV];
+            requestOld(0, oldv[0]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c + 1 < 4) requestOld(c + 1, oldv[(c + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int t = 0; t < KV; ++t) {
                     const int m = 4 * t + static_cast<int>(q);
                     if (m >= Np) continue;
-                    if (slot >= 0) { // element of curvedEls: its own mass matrix is applied by the fix-up kernel
-                        p.mmSide[(static_cast<long long>(c) * Np + m) * p.sideLd + slot] = acc[c][t >> 2][t & 3];
-                        continue;
-                    }
                     double R = out[c][t >> 2][t & 3];
                     if constexpr (!FILTER) R += c == 1 ? S2[t] : (c == 2 ? S3[t] : 0.0);
+                    const unsigned vo = store ? v8 : 0xfffffff8u; // (an out-of-range offset drops the store)
                     const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
                     if constexpr (MODE == CMODE_RHS) {
-                        cbst_f64(rout, v8, so, R);
+                        cbst_f64(rout, vo, so, R);
                     } else if constexpr (MODE == CMODE_LSERK) {
-                        const double n1 = p.ca * cbld_f64(rold, v8, so) + p.cc * R;
-                        cbst_f64(rold, v8, so, n1); // the residual, in place
-                        cbst_f64(rout, v8, so, qB[c][t] + p.cb * n1);
+                        const double n1 = p.ca * oldv[c & 1][t] + p.cc * R;
+                        cbst_f64(rold, vo, so, n1); // the residual, in place
+                        cbst_f64(rout, vo, so, qB[c][t] + p.cb * n1);
                     } else {
-                        cbst_f64(rout, v8, so, p.ca * cbld_f64(rold, v8, so) + p.cb * qB[c][t] + p.cc * R);
+                        cbst_f64(rout, vo, so, p.ca * oldv[c & 1][t] + p.cb * qB[c][t] + p.cc * R);
                     }
                 }
-        }
+            }
+        };
+        if (affTile) body(std::true_type{});
+        else body(std::false_type{});
     }
 }
 

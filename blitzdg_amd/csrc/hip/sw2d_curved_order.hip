@@ -136,9 +136,10 @@ bool ntFits(int ncb, int fb, bool filter) {
                                : ntLdsResident(ncb, fb) <= static_cast<size_t>(kLdsBudgetBytes);
 }
 
-template <int MODE, bool FILTER, int STREAM, int FB, int WAVES>
+template <int MODE, bool FILTER, int STREAM, int FB, int RL>
 hipError_t launchNT(const CurvedParams& p, hipStream_t stream, size_t lds) {
-    auto kern = sw2d_curved_nt_kernel<kN, MODE, FILTER, STREAM, FB, WAVES>;
+    constexpr int WAVES = kDefaultWaves;
+    auto kern = sw2d_curved_nt_kernel<kN, MODE, FILTER, STREAM, FB, WAVES, RL>;
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  static_cast<int>(lds));
@@ -152,23 +153,29 @@ hipError_t launchNT(const CurvedParams& p, hipStream_t stream, size_t lds) {
     return hipGetLastError();
 }
 
+// Compiled shapes of the face blocks: the builders' default rule NGauss = 2 (N + 1) exactly -- FB blocks per face, RL live 4-row
+// steps in the last one -- and the two general shapes (every step of one / two blocks) for any other rule.
+constexpr int kNgDef = 2 * (BDG_ORDER + 1), kFbDef = (kNgDef + 15) / 16, kRlDef = (kNgDef - 16 * (kFbDef - 1) + 3) / 4;
+
+template <int MODE, bool FILTER, int STREAM>
+hipError_t launchShape(const CurvedParams& p, hipStream_t stream, size_t lds) {
+    const int rl = (p.ng - 16 * (p.fb - 1) + 3) / 4;
+    if (p.fb == kFbDef && rl == kRlDef) return launchNT<MODE, FILTER, STREAM, kFbDef, kRlDef>(p, stream, lds);
+    if (p.fb == 1) return launchNT<MODE, FILTER, STREAM, 1, 4>(p, stream, lds);
+    return launchNT<MODE, FILTER, STREAM, 2, 4>(p, stream, lds);
+}
+
 template <int MODE, bool FILTER>
 hipError_t launchStageNT(const CurvedParams& p, hipStream_t stream) {
     if (p.K < 1) return hipSuccess;
-    const bool two = curvedWaves() == 2, streamed = ntStreamed(p.ncb, p.fb);
+    const bool streamed = ntStreamed(p.ncb, p.fb);
     const size_t lds = streamed ? ntLdsStreamed(p.ncb, p.fb, FILTER) : ntLdsResident(p.ncb, p.fb);
     if (lds > kLdsLimitBytes || p.fb < 1 || p.fb > 2) return hipErrorInvalidValue; // (ntFits was asked at creation)
     if (streamed) {
-        if constexpr (kNtStream) {
-            if (p.fb == 1) return two ? launchNT<MODE, FILTER, 1, 1, 2>(p, stream, lds) : launchNT<MODE, FILTER, 1, 1, 1>(p, stream, lds);
-            return two ? launchNT<MODE, FILTER, 1, 2, 2>(p, stream, lds) : launchNT<MODE, FILTER, 1, 2, 1>(p, stream, lds);
-        }
+        if constexpr (kNtStream) return launchShape<MODE, FILTER, 1>(p, stream, lds);
         return hipErrorInvalidValue;
     }
-    if constexpr (kNtResident) {
-        if (p.fb == 1) return two ? launchNT<MODE, FILTER, 0, 1, 2>(p, stream, lds) : launchNT<MODE, FILTER, 0, 1, 1>(p, stream, lds);
-        return two ? launchNT<MODE, FILTER, 0, 2, 2>(p, stream, lds) : launchNT<MODE, FILTER, 0, 2, 1>(p, stream, lds);
-    }
+    if constexpr (kNtResident) return launchShape<MODE, FILTER, 0>(p, stream, lds);
     return hipErrorInvalidValue;
 }
 
