@@ -79,7 +79,7 @@ struct bdg_sw2d_curved {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     size_t bytes = 0;
-    Buf<double> qA, qB, res, rhs, gq, cubG, gaussG, coef, mmSide, cholSide, ops, filt;
+    Buf<double> qA, qB, res, rhs, gq, cubG, gaussG, coef, mmSide, minvSide, ops, filt;
     // nodal coefficient planes inside coef (one allocation: the stage kernel reaches all of them through one buffer
     // descriptor): 1 / J first, then whichever of zx, zy, f, CD the caller gave (nullptr: absent)
     double *rJ = nullptr, *zx = nullptr, *zy = nullptr, *fcor = nullptr, *cd = nullptr;
@@ -122,7 +122,7 @@ struct bdg_sw2d_curved {
         p.gq = gq.p; p.cubG = cubG.p; p.gaussG = gaussG.p; p.gmapP = gmapP.p; p.gmapM = identityM ? nullptr : gmapM.p;
         p.rJ = rJ; p.zx = zx; p.zy = zy; p.fcor = fcor; p.cd = cd; p.fconst = fconst; p.cdconst = cdconst;
         p.curvedSlot = numCurved ? curvedSlot.p : nullptr;
-        p.mmSide = mmSide.p; p.cholSide = cholSide.p; p.curvedEls = curvedEls.p; p.numCurved = numCurved; p.sideLd = sideLd;
+        p.mmSide = mmSide.p; p.minvSide = minvSide.p; p.curvedEls = curvedEls.p; p.numCurved = numCurved; p.sideLd = sideLd;
         p.affineEl = numAffine ? affineEl.p : nullptr; p.cubAffine = numAffine ? cubAffine.p : nullptr; p.cubWref = cubWref.p;
         p.ops = ops.p; p.filt = filt.p; p.ld = ld; p.K = K; p.ncb = ncb; p.ncub = ncub; p.ng = ng; p.fb = fb; p.g = g;
         if (useNT) {
@@ -602,20 +602,38 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         hipOk(hipMemcpyAsync(s->curvedSlot.p, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice, st), "slot upload");
         s->curvedEls.alloc(curved.size(), s->bytes, st);
         hipOk(hipMemcpyAsync(s->curvedEls.p, curved.data(), curved.size() * sizeof(int), hipMemcpyHostToDevice, st), "curvedEls upload");
-        const size_t sld = static_cast<size_t>(s->sideLd);
-        std::vector<double> chol(static_cast<size_t>(Np) * Np * sld, 0.0);
-        for (size_t c = 0; c < curved.size(); ++c)
-            for (int i = 0; i < Np; ++i) {
-                for (int jj = 0; jj < Np; ++jj)
-                    chol[(static_cast<size_t>(i) * Np + jj) * sld + c] = d.MMChol[(static_cast<size_t>(i) * Np + jj) * K + curved[c]];
-                const double dii = d.MMChol[(static_cast<size_t>(i) * Np + i) * K + curved[c]];
-                if (!(dii > 0.0))
-                    throw arg_error("bdg_sw2d_curved_create: MMChol has a non-positive diagonal entry on an element of curvedEls");
-                chol[(static_cast<size_t>(i) * Np + i) * sld + c] = 1.0 / dii; // the solves multiply by 1 / U_ii
+        // inverse mass matrix of every listed element from its upper Cholesky factor U (M = U^T U): W = U^-1 by back
+        // substitution, Minv = W W^T (the reference solves U^T y = b, U x = y per evaluation, rhs.py:157-162)
+        std::vector<double> minv(static_cast<size_t>(Np) * Np * curved.size(), 0.0);
+        std::atomic<bool> badDiagonal{false};
+        blitzdg::detail::parallelChunks(static_cast<int>(curved.size()), [&](int cBegin, int cEnd) {
+            std::vector<double> U(static_cast<size_t>(Np) * Np), W(static_cast<size_t>(Np) * Np);
+            for (int c = cBegin; c < cEnd; ++c) {
+                for (int i = 0; i < Np; ++i)
+                    for (int jj = 0; jj < Np; ++jj) U[static_cast<size_t>(i) * Np + jj] = d.MMChol[(static_cast<size_t>(i) * Np + jj) * K + curved[c]];
+                std::fill(W.begin(), W.end(), 0.0);
+                for (int jj = 0; jj < Np; ++jj) { // column jj of W: U w = e_jj, from row jj upwards
+                    if (!(U[static_cast<size_t>(jj) * Np + jj] > 0.0)) { badDiagonal = true; break; }
+                    W[static_cast<size_t>(jj) * Np + jj] = 1.0 / U[static_cast<size_t>(jj) * Np + jj];
+                    for (int i = jj - 1; i >= 0; --i) {
+                        double sum = 0.0;
+                        for (int m = i + 1; m <= jj; ++m) sum += U[static_cast<size_t>(i) * Np + m] * W[static_cast<size_t>(m) * Np + jj];
+                        W[static_cast<size_t>(i) * Np + jj] = -sum / U[static_cast<size_t>(i) * Np + i];
+                    }
+                }
+                double* out = minv.data() + static_cast<size_t>(c) * Np * Np;
+                for (int i = 0; i < Np; ++i)
+                    for (int jj = i; jj < Np; ++jj) {
+                        double sum = 0.0;
+                        for (int m = jj; m < Np; ++m) sum += W[static_cast<size_t>(i) * Np + m] * W[static_cast<size_t>(jj) * Np + m];
+                        out[static_cast<size_t>(i) * Np + jj] = out[static_cast<size_t>(jj) * Np + i] = sum;
+                    }
             }
-        s->cholSide.alloc(chol.size(), s->bytes, st);
-        hipOk(hipMemcpyAsync(s->cholSide.p, chol.data(), chol.size() * sizeof(double), hipMemcpyHostToDevice, st), "chol upload");
-        s->mmSide.alloc(static_cast<size_t>(4) * Np * sld, s->bytes, st);
+        }, 8);
+        if (badDiagonal) throw arg_error("bdg_sw2d_curved_create: MMChol has a non-positive diagonal entry on an element of curvedEls");
+        s->minvSide.alloc(minv.size(), s->bytes, st);
+        hipOk(hipMemcpyAsync(s->minvSide.p, minv.data(), minv.size() * sizeof(double), hipMemcpyHostToDevice, st), "Minv upload");
+        s->mmSide.alloc(static_cast<size_t>(4) * Np * curved.size(), s->bytes, st);
         hipOk(hipStreamSynchronize(st), "side upload sync");
     }
 

@@ -21,8 +21,8 @@
 //   sw2d_curved_stage_kernel   everything above + RK update; neighbour traces gathered from gq through gmapP
 //                              (any map: periodic rewiring included); elements of curvedEls leave their raw MM_c
 //                              in a side buffer instead
-//   sw2d_curved_fixup_kernel   the elements of curvedEls: two triangular solves with their own Cholesky factor,
-//                              sources, filter, update (one lane per element; they are the few boundary elements)
+//   sw2d_curved_fixup_kernel   the elements of curvedEls: their own inverse mass matrix (U^-1 U^-T of their Cholesky factor,
+//                              formed at creation) applied as one dense product, sources, filter, update
 // Tables are (rows, ld) planes, element index contiguous; a wave touches 128-byte row segments.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -60,8 +60,8 @@ struct CurvedParams {
     const double* cd;     // Np*ld or nullptr (then cdconst)
     double fconst, cdconst;
     const int* curvedSlot; // ld: index into the side buffer for elements of curvedEls, -1 otherwise (nullptr: none)
-    double* mmSide;        // 4*Np rows of sideLd: raw MM_c of the curved elements
-    const double* cholSide; // Np*Np rows of sideLd: their upper Cholesky factors
+    double* mmSide;        // (numCurved, 4, Np): raw MM_c of the elements of curvedEls
+    const double* minvSide; // (numCurved, Np, Np): their inverse mass matrices U^-1 U^-T (from cub_ctx.MMChol)
     const int* curvedEls;  // element slot of each side-buffer column
     int numCurved;
     long long sideLd;
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
                     const int m = 4 * t + static_cast<int>(q);
                     if (m >= Np) continue;
                     if (slot >= 0) { // element of curvedEls: its own mass matrix is applied by the fix-up kernel
-                        p.mmSide[(static_cast<long long>(c) * Np + m) * p.sideLd + slot] = acc[c][t >> 2][t & 3];
+                        p.mmSide[(static_cast<size_t>(slot) * 4 + c) * Np + m] = acc[c][t >> 2][t & 3];
                         continue;
                     }
                     double R = out[c][t >> 2][t & 3];
@@ -561,77 +561,65 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_stage_kernel(const Cur
 }
 
 // ---- elements of curvedEls: RHS_c = U^-1 U^-T MM_c with the element's own Cholesky factor (rhs.py:157-162), then
-// sources, filter and update as above. One lane per (element, field); columns of the side buffers are contiguous in the
-// element slot, so a wave's loads of one matrix entry are coalesced, and a whole row of U is requested at once
-// (2 Np round trips per solve instead of Np^2). cholSide holds 1 / U_ii on the diagonal.
+// sources, filter and update as above. The inverse mass matrix Minv = U^-1 U^-T of every listed element is formed once at
+// creation (minvSide, (Np, Np) per element, symmetric), so the two triangular solves -- 2 Np dependent steps per lane,
+// 0.22 ms for 3000 elements at N = 8 in the first version -- are one dense product: lane i of an element's group of P lanes
+// owns node i, reads column i of Minv (coalesced: row m of a symmetric matrix) and takes MM_c(m) from lane m by a
+// shuffle; the same for Filter. 64 / P elements per wave (P = 16, 32 or 64 lanes >= Np).
 template <int N, int MODE, bool FILTER>
 __global__ __launch_bounds__(64) void sw2d_curved_fixup_kernel(const CurvedParams p) {
-    constexpr int Np = (N + 1) * (N + 2) / 2;
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
-    if (slot >= p.numCurved) return;
+    constexpr int Np = (N + 1) * (N + 2) / 2, P = Np <= 16 ? 16 : (Np <= 32 ? 32 : 64), EPW = 64 / P;
+    const int lane = static_cast<int>(threadIdx.x), e = lane / P, i = lane % P, first = e * P;
+    const int slotTrue = static_cast<int>(blockIdx.x) * EPW + e;
+    const bool has = slotTrue < p.numCurved, mine = has && i < Np;
+    const int slot = has ? slotTrue : p.numCurved - 1, ic = i < Np ? i : Np - 1; // (clamped: every lane reads valid memory)
     const unsigned k = static_cast<unsigned>(p.curvedEls[slot]), k8 = k * 8u;
-    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld, sld = p.sideLd;
-    const double* __restrict__ U = p.cholSide + slot; // U[i][j] at U[(i*Np + j) * sld]
-    double x[Np];
+    const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
+    const double* __restrict__ Mi = p.minvSide + static_cast<size_t>(slot) * Np * Np;
+    double x[4], y[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int m = 0; m < Np; ++m) x[m] = p.mmSide[(static_cast<long long>(c) * Np + m) * sld + slot];
-    // U^T y = b, column-oriented: y_j = b_j / U_jj, then b_i -= U_ji y_j for i > j (row j of U in one batch of loads)
-#pragma unroll 1
-    for (int jj = 0; jj < Np; ++jj) {
-        double row[Np];
+    for (int c = 0; c < 4; ++c) x[c] = p.mmSide[(static_cast<size_t>(slot) * 4 + c) * Np + ic];
+    // this node's state and source tables (requested with the matrix rows)
+    const long long rowOff = static_cast<long long>(ic) * ld;
+    const double h = cld_row(p.qin + rowOff, k8), hu = cld_row(p.qin + plane + rowOff, k8), hv = cld_row(p.qin + 2 * plane + rowOff, k8);
+#pragma unroll 5
+    for (int m = 0; m < Np; ++m) {
+        const double a = Mi[m * Np + ic];
 #pragma unroll
-        for (int i = 0; i < Np; ++i) row[i] = U[(static_cast<long long>(jj) * Np + i) * sld];
-        double yj = 0.0;
-#pragma unroll
-        for (int i = 0; i < Np; ++i) yj = i == jj ? x[i] * row[i] : yj;
-#pragma unroll
-        for (int i = 0; i < Np; ++i) x[i] = i == jj ? yj : (i > jj ? fma(-row[i], yj, x[i]) : x[i]);
+        for (int c = 0; c < 4; ++c) y[c] = fma(a, __shfl(x[c], first + m), y[c]);
     }
-    // U x = y, row-oriented from the last row: x_i = (y_i - sum_{j > i} U_ij x_j) / U_ii
-#pragma unroll 1
-    for (int i = Np - 1; i >= 0; --i) {
-        double row[Np];
-#pragma unroll
-        for (int jj = 0; jj < Np; ++jj) row[jj] = U[(static_cast<long long>(i) * Np + jj) * sld];
-        double sacc = 0.0, yi = 0.0, rd = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < Np; ++jj) {
-            sacc = jj > i ? fma(row[jj], x[jj], sacc) : sacc;
-            yi = jj == i ? x[jj] : yi;
-            rd = jj == i ? row[jj] : rd;
-        }
-        const double xi = (yi - sacc) * rd;
-#pragma unroll
-        for (int jj = 0; jj < Np; ++jj) x[jj] = jj == i ? xi : x[jj];
+    {
+        double S2, S3;
+        curved_sources(p, h, hu, hv, rowOff, k8, S2, S3);
+        y[1] += S2;
+        y[2] += S3;
     }
-    if (c == 1 || c == 2) {
+    double r[4];
+    if constexpr (FILTER) {
 #pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] = 0.0;
+#pragma unroll 5
         for (int m = 0; m < Np; ++m) {
-            double S2, S3;
-            curved_sources(p, cld_row(p.qin + m * ld, k8), cld_row(p.qin + plane + m * ld, k8),
-                           cld_row(p.qin + 2 * plane + m * ld, k8), m * ld, k8, S2, S3);
-            x[m] += c == 1 ? S2 : S3;
+            const double a = p.filt[ic * Np + m];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = fma(a, __shfl(y[c], first + m), r[c]);
         }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) r[c] = y[c];
     }
-#pragma unroll 1
-    for (int i = 0; i < Np; ++i) {
-        double r = 0.0;
-        if constexpr (FILTER) {
+    if (!mine) return;
 #pragma unroll
-            for (int m = 0; m < Np; ++m) r = fma(p.filt[i * Np + m], x[m], r);
-        } else {
-#pragma unroll
-            for (int m = 0; m < Np; ++m) r = m == i ? x[m] : r;
-        }
-        const long long off = c * plane + i * ld;
+    for (int c = 0; c < 4; ++c) {
+        const long long off = c * plane + rowOff;
         if constexpr (MODE == CMODE_RHS) {
-            cst_row(p.rhs + off, k8, r);
+            cst_row(p.rhs + off, k8, r[c]);
         } else if constexpr (MODE == CMODE_LSERK) {
-            const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * r;
+            const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * r[c];
             cst_row(p.res + off, k8, n1);
             cst_row(p.qout + off, k8, cld_row(p.qin + off, k8) + p.cb * n1);
         } else {
-            cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * cld_row(p.qin + off, k8) + p.cc * r);
+            cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * cld_row(p.qin + off, k8) + p.cc * r[c]);
         }
     }
 }

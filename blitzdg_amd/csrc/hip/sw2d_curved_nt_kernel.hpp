@@ -271,26 +271,32 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
             for (int f = 0; f < 3; ++f) {
                 const bool wall = (flags >> f) & 1;
                 const double fnx = fa[0], fny = fa[1], fw = fa[2];
-                cmfma_t gP[FB][4];
-#pragma unroll
-                for (int b = 0; b < FB; ++b) {
+                // One block per face: the exterior traces first, then the next face's nodes are requested while this face is
+                // worked on. Two blocks: each block forms its own exterior traces (16 fewer live doubles) and the request follows
+                // the last block's pointwise work, behind the face's lift products.
+                cmfma_t gP[4];
+                auto exteriorTraces = [&](int b) {
                     const int sbase = ldsSurf + (f * FB + b) * SCH;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) gP[b][c] = cmfma_zero();
+                    for (int c = 0; c < 4; ++c) gP[c] = cmfma_zero();
 #pragma unroll
                     for (int t2 = 0; t2 < KE; ++t2) {
                         const double a = L(sbase + KV + t2);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) gP[b][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qP[c][t2], gP[b][c], 0, 0, 0);
+                        for (int c = 0; c < 4; ++c) gP[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qP[c][t2], gP[c], 0, 0, 0);
                     }
+                };
+                if constexpr (FB == 1) {
+                    exteriorTraces(0);
+                    if (f < 2) gather(f + 1, qP, fa);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (f < 2) gather(f + 1, qP, fa); // the next face's nodes while this face is worked on (qP's products are issued)
-                __builtin_amdgcn_sched_barrier(0);
                 double lam = 0.0;
                 double ef[FB][4][4], dj[FB][4][4];
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
                     const int gb = f * FB + b;
+                    if constexpr (FB > 1) exteriorTraces(b);
                     cmfma_t gM[4]; // the element's own traces at this block's 16 Gauss rows
                     {
                         const int sbase = ldsSurf + gb * SCH;
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                             hW = 0.5 * cbld_f64(rgg, v8, 2u * gplaneB + so8); // zero on padding rows
                         }
                         double hM = gM[0][reg], huM = gM[1][reg], hvM = gM[2][reg], hNM = gM[3][reg];
-                        double hP = gP[b][0][reg], huP = gP[b][1][reg], hvP = gP[b][2][reg], hNP = gP[b][3][reg];
+                        double hP = gP[0][reg], huP = gP[1][reg], hvP = gP[2][reg], hNP = gP[3][reg];
                         if (!valid) { hM = 1.0; hP = 1.0; huM = hvM = hNM = huP = hvP = hNP = 0.0; }
                         const double rM = crcp(hM), rP = crcp(hP);
                         // the wave speeds use the exterior velocity BEFORE the wall condition (rhs.py:81-85, :93-94)
@@ -340,10 +346,16 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                             ef[b][reg][c] = hW * (F[c] * nx + G[c] * ny);
                             dj[b][reg][c] = hW * dq[c];
                         }
+                        // one Gauss row at a time at high order: interleaved, the rows' temporaries do not fit beside 2 x 48 resident doubles
+                        if constexpr (KV > 8) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 lam = fmax(lam, __shfl_xor(lam, 16)); // the face's Gauss points sit in the 4 lanes q of this element
                 lam = fmax(lam, __shfl_xor(lam, 32));
+                if constexpr (FB > 1) {
+                    if (f < 2) gather(f + 1, qP, fa);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int b = 0; b < FB; ++b)
 #pragma unroll
@@ -363,13 +375,10 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
 
             // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
             const int slot = p.curvedSlot ? p.curvedSlot[k] : -1;
-            cmfma_t out[4][MT];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int r = 0; r < MT; ++r) out[c][r] = cmfma_zero();
             // Rows of this phase -- the source tables, 1 / J on general tiles, the residual / base state of the update -- are
             // requested TC k-steps (one field) ahead of their use: everything at once is 17 rows per k-step, 400 registers at N = 8.
+            // Order: sources at every node first (S2, S3), then ONE field at a time: mass products (and Filter S for the momentum
+            // fields), update, stores -- MT result tiles live instead of 4 MT.
             constexpr int TC = KV < 4 ? KV : 4, NCH = (KV + TC - 1) / TC;
             struct Rows { double cf[TC], cd[TC], zx[TC], zy[TC], rj[TC]; };
             auto requestRows = [&](int ch, Rows& w) {
@@ -385,16 +394,26 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                     w.zy[i] = p.zy ? cbld_f64(rcoef, vo, soZy + so) : 0.0;
                 }
             };
-            auto requestOld = [&](int c, double (&o)[KV]) {
+            // At high order the update reads the element's own state again (an L2 hit, requested with the residual rows) instead
+            // of holding all 4 KV operand registers to the end of the tile: the compiler kept them in scratch, and every reload
+            // of a spilled register waits for ALL requests in flight.
+            constexpr bool REQ = KV > 8 && MODE != CMODE_RHS;
+            auto requestOld = [&](int c, double (&o)[KV], double (&own)[REQ ? KV : 1]) {
                 if constexpr (MODE != CMODE_RHS) {
 #pragma unroll
-                    for (int t = 0; t < KV; ++t) o[t] = cbld_f64(rold, v8, static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8);
+                    for (int t = 0; t < KV; ++t) {
+                        const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
+                        o[t] = cbld_f64(rold, v8, so);
+                        if constexpr (REQ) own[t] = cbld_f64(rq, v8, so);
+                    }
                 }
             };
             Rows rows[2];
             requestRows(0, rows[0]);
+            double oldv[2][KV], ownv[2][REQ ? KV : 1];
+            requestOld(0, oldv[0], ownv[0]);
             __builtin_amdgcn_sched_barrier(0);
-            double S2[KV], S3[KV];
+            double S2[KV], S3[KV], rjn[AFF ? 1 : KV];
 #pragma unroll
             for (int ch = 0; ch < NCH; ++ch) {
                 if (ch + 1 < NCH) requestRows(ch + 1, rows[(ch + 1) & 1]);
@@ -405,36 +424,14 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                     const int t = ch * TC + i;
                     if (t >= KV) break;
                     const int m = 4 * t + static_cast<int>(q);
-                    const double rj = AFF ? (m < Np ? ea[4] : 0.0) : w.rj[i];
-#pragma unroll
-                    for (int r = 0; r < MT; ++r) {
-                        const double a = L(ldsMass + r * KV + t);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            out[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, acc[c][t >> 2][t & 3] * rj, out[c][r], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < TC; ++i) {
-                    const int t = ch * TC + i;
-                    if (t >= KV) break;
-                    const int m = 4 * t + static_cast<int>(q);
-                    {   // momentum sources at the node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx, S3 = -(f hu - CD |u| v) - g h zy
-                        const double h = m < Np ? qB[0][t] : 1.0, hu = qB[1][t], hv = qB[2][t];
-                        const double rh = crcp(h);
-                        const double u = hu * rh, v = hv * rh;
-                        const double cdn = w.cd[i] * csqrt(u * u + v * v);
-                        S2[t] = m < Np ? (w.cf[i] * hv - cdn * u) - g * h * w.zx[i] : 0.0;
-                        S3[t] = m < Np ? -(w.cf[i] * hu - cdn * v) - g * h * w.zy[i] : 0.0;
-                    }
-                    if constexpr (FILTER) {
-#pragma unroll
-                        for (int r = 0; r < MT; ++r) {
-                            const double af = L(ldsF + r * KV + t);
-                            out[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S2[t], out[1][r], 0, 0, 0);
-                            out[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(af, S3[t], out[2][r], 0, 0, 0);
-                        }
-                    }
+                    if constexpr (!AFF) rjn[t] = w.rj[i];
+                    // momentum sources at the node (rhs.py:165-174): S2 = f hv - CD |u| u - g h zx, S3 = -(f hu - CD |u| v) - g h zy
+                    const double h = m < Np ? qB[0][t] : 1.0, hu = qB[1][t], hv = qB[2][t];
+                    const double rh = crcp(h);
+                    const double u = hu * rh, v = hv * rh;
+                    const double cdn = w.cd[i] * csqrt(u * u + v * v);
+                    S2[t] = m < Np ? (w.cf[i] * hv - cdn * u) - g * h * w.zx[i] : 0.0;
+                    S3[t] = m < Np ? -(w.cf[i] * hu - cdn * v) - g * h * w.zy[i] : 0.0;
                 }
             }
             if (live && slot >= 0) { // element of curvedEls: its own mass matrix is applied by the fix-up kernel
@@ -443,32 +440,53 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
 #pragma unroll
                     for (int t = 0; t < KV; ++t) {
                         const int m = 4 * t + static_cast<int>(q);
-                        if (m < Np) p.mmSide[(static_cast<long long>(c) * Np + m) * p.sideLd + slot] = acc[c][t >> 2][t & 3];
+                        if (m < Np) p.mmSide[(static_cast<size_t>(slot) * 4 + c) * Np + m] = acc[c][t >> 2][t & 3];
                     }
             }
             const bool store = live && slot < 0;
-            double oldv[2][KV];
-            requestOld(0, oldv[0]);
+            const unsigned vo = store ? v8 : 0xfffffff8u; // (an out-of-range offset drops the store)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (c + 1 < 4) requestOld(c + 1, oldv[(c + 1) & 1]);
+                if (c + 1 < 4) requestOld(c + 1, oldv[(c + 1) & 1], ownv[(c + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
+                cmfma_t out[MT];
+#pragma unroll
+                for (int r = 0; r < MT; ++r) out[r] = cmfma_zero();
+#pragma unroll
+                for (int t = 0; t < KV; ++t) {
+                    const int m = 4 * t + static_cast<int>(q);
+                    double rj;
+                    if constexpr (AFF) rj = m < Np ? ea[4] : 0.0;
+                    else rj = rjn[t];
+                    const double b = acc[c][t >> 2][t & 3] * rj;
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) out[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(L(ldsMass + r * KV + t), b, out[r], 0, 0, 0);
+                    if constexpr (FILTER) {
+                        if (c == 1 || c == 2) {
+                            const double sv = c == 1 ? S2[t] : S3[t];
+#pragma unroll
+                            for (int r = 0; r < MT; ++r) out[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(L(ldsF + r * KV + t), sv, out[r], 0, 0, 0);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int t = 0; t < KV; ++t) {
                     const int m = 4 * t + static_cast<int>(q);
                     if (m >= Np) continue;
-                    double R = out[c][t >> 2][t & 3];
+                    double R = out[t >> 2][t & 3];
                     if constexpr (!FILTER) R += c == 1 ? S2[t] : (c == 2 ? S3[t] : 0.0);
-                    const unsigned vo = store ? v8 : 0xfffffff8u; // (an out-of-range offset drops the store)
                     const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
+                    double own = 0.0;
+                    if constexpr (REQ) own = ownv[c & 1][t];
+                    else if constexpr (MODE != CMODE_RHS) own = qB[c][t];
                     if constexpr (MODE == CMODE_RHS) {
                         cbst_f64(rout, vo, so, R);
                     } else if constexpr (MODE == CMODE_LSERK) {
                         const double n1 = p.ca * oldv[c & 1][t] + p.cc * R;
                         cbst_f64(rold, vo, so, n1); // the residual, in place
-                        cbst_f64(rout, vo, so, qB[c][t] + p.cb * n1);
+                        cbst_f64(rout, vo, so, own + p.cb * n1);
                     } else {
-                        cbst_f64(rout, vo, so, p.ca * oldv[c & 1][t] + p.cb * qB[c][t] + p.cc * R);
+                        cbst_f64(rout, vo, so, p.ca * oldv[c & 1][t] + p.cb * own + p.cc * R);
                     }
                 }
             }

@@ -96,7 +96,8 @@ hipError_t stage(int mode, bool filter, const CurvedParams& p, hipStream_t strea
 template <int MODE, bool FILTER>
 hipError_t launchFixup(const CurvedParams& p, hipStream_t stream) {
     if (p.numCurved < 1) return hipSuccess;
-    hipLaunchKernelGGL((sw2d_curved_fixup_kernel<kN, MODE, FILTER>), dim3((p.numCurved + 63) / 64, 4), dim3(64), 0, stream, p);
+    constexpr int P = O::Np <= 16 ? 16 : (O::Np <= 32 ? 32 : 64), EPW = 64 / P; // elements per wave (sw2d_curved_fixup_kernel)
+    hipLaunchKernelGGL((sw2d_curved_fixup_kernel<kN, MODE, FILTER>), dim3((p.numCurved + EPW - 1) / EPW), dim3(64), 0, stream, p);
     return hipGetLastError();
 }
 
