@@ -213,19 +213,34 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                     base = O::offVol(rb);
                 }
                 if (act) {
+                    // A tiles are read from LDS one phase AHEAD of the products that use them (all KV interpolation tiles before the
+                    // first product; the 2 MT DrT / DsT tiles of step reg + 1 before the pointwise work of step reg): left to
+                    // itself the compiler reads a tile, waits for it and issues its 4..8 products, exposing the LDS latency every time.
+                    double aV[KV], aD[2][2 * MT];
+#pragma unroll
+                    for (int t = 0; t < KV; ++t) aV[t] = L(base + t);
+#pragma unroll
+                    for (int r = 0; r < MT; ++r) { aD[0][r] = L(base + KV + r * 4); aD[0][MT + r] = L(base + KV + 4 * MT + r * 4); }
+                    __builtin_amdgcn_sched_barrier(0);
                     cmfma_t cv[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) cv[c] = cmfma_zero();
 #pragma unroll
                     for (int t = 0; t < KV; ++t) {
-                        const double a = L(base + t);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) cv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], cv[c], 0, 0, 0);
+                        for (int c = 0; c < 4; ++c) cv[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aV[t], qB[c][t], cv[c], 0, 0, 0);
                     }
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) { // 4 cubature points of this lane = contraction step reg of DrT / DsT
                         const int row = 16 * rb + static_cast<int>(q) + 4 * reg;
                         const unsigned so = static_cast<unsigned>(16 * rb + 4 * reg) * ld8;
+                        if (reg + 1 < 4) {
+#pragma unroll
+                            for (int r = 0; r < MT; ++r) {
+                                aD[(reg + 1) & 1][r] = L(base + KV + r * 4 + reg + 1);
+                                aD[(reg + 1) & 1][MT + r] = L(base + KV + 4 * MT + r * 4 + reg + 1);
+                            }
+                        }
                         double wrx, wry, wsx, wsy;
                         if constexpr (AFF) { // rule weight (times a reference Jacobian) of this point, the element's four numbers
                             const double w = sOps[wrefAt + row]; // zero on padding rows
@@ -234,6 +249,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                             wrx = cbld_f64(rcub, v8, so); wry = cbld_f64(rcub, v8, cplaneB + so);
                             wsx = cbld_f64(rcub, v8, 2u * cplaneB + so); wsy = cbld_f64(rcub, v8, 3u * cplaneB + so);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                         const bool valid = row < p.ncub;
                         const CurvedFlux fl = curved_fluxes(valid ? cv[0][reg] : 1.0, cv[1][reg], cv[2][reg], cv[3][reg], g);
                         double tr[4], ts[4];
@@ -244,7 +260,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                         }
 #pragma unroll
                         for (int r = 0; r < MT; ++r) {
-                            const double aDr = L(base + KV + r * 4 + reg), aDs = L(base + KV + 4 * MT + r * 4 + reg);
+                            const double aDr = aD[reg & 1][r], aDs = aD[reg & 1][MT + r];
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
                                 acc[c][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(aDr, tr[c], acc[c][r], 0, 0, 0);
@@ -300,13 +316,16 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                     cmfma_t gM[4]; // the element's own traces at this block's 16 Gauss rows
                     {
                         const int sbase = ldsSurf + gb * SCH;
+                        double aG[KV];
+#pragma unroll
+                        for (int t = 0; t < KV; ++t) aG[t] = L(sbase + t);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int c = 0; c < 4; ++c) gM[c] = cmfma_zero();
 #pragma unroll
                         for (int t = 0; t < KV; ++t) {
-                            const double a = L(sbase + t);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qB[c][t], gM[c], 0, 0, 0);
+                            for (int c = 0; c < 4; ++c) gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aG[t], qB[c][t], gM[c], 0, 0, 0);
                         }
                     }
 #pragma unroll

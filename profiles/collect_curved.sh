@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 evidence for the curved / over-integrated RHS (profiles/time_curved.py) on the GPU box:
-#   bash profiles/collect_curved.sh r03_curved_n4 4 500 250
+#   bash profiles/collect_curved.sh r03_curved_n4 4 500 250 [kernel-name substring, default sw2d_curved_nt_kernel]
 # Kernel trace / stats and every PMC group are SEPARATE rocprofv3 runs of the same command (PMC passes never
 # combine with trace domains). Raw output: gpurun_out/prof_<tag>_*; summary: profiles/<tag>_{pmc_summary.json,kernel_stats.csv}
 set -euo pipefail
-TAG=$1; ORDER=$2; NX=$3; NY=$4
+TAG=$1; ORDER=$2; NX=$3; NY=$4; KERNEL=${5:-sw2d_curved_nt_kernel}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out
 mkdir -p "$OUT"
@@ -21,5 +21,5 @@ for group in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum
   name=${group%%:*}; ctrs=${group#*:}
   timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$OUT/prof_${TAG}_${name}" -- $CMD 10 > "$OUT/prof_${TAG}_${name}.log" 2>&1 || true
 done
-python3 "$R/profiles/summarize.py" "$TAG" "$OUT" --into "$OUT/summaries" --kernel sw2d_curved_stage > "$OUT/prof_${TAG}_summary.txt" 2>&1 || true
+python3 "$R/profiles/summarize.py" "$TAG" "$OUT" --into "$OUT/summaries" --kernel "$KERNEL" > "$OUT/prof_${TAG}_summary.txt" 2>&1 || true
 tail -60 "$OUT/prof_${TAG}_summary.txt"
