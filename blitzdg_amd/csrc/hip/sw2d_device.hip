@@ -514,6 +514,20 @@ struct bdg_sw2d {
     // resident-workgroup kernels, interior launch of a partitioned run: CUs left to the boundary kernel (a strip of a few
     // hundred elements = 4..8 four-wave workgroups); N=8, 8-way rehearsal: 0.087 -> see profiles/r02_rehearsal.txt
     static constexpr int kInteriorGridCap = 244;
+    // ... and at N >= 5 the strip kernel's workgroups (one 16-element tile each, three waves; none fits beside an interior
+    // workgroup's 120 KB of LDS) need free CUs, or the strip -- which sits on the exchange chain -- runs in several rounds
+    // (N=8, 8-way rehearsal, 24 tiles on the 12 CUs the fixed cap left free: 27 us; on 24 free CUs 18 us). So the interior
+    // leaves one CU per strip tile, at most a quarter of the chip. Measured per stage in the 8-way rehearsal
+    // (profiles/r03_rehearsal.txt): N=5 0.061 -> 0.058 ms, N=6 0.058 -> 0.055, N=7 0.052 -> 0.049, N=8 0.065 -> 0.063 (there
+    // the interior pays it back: 1930 tiles on 232 workgroups are three rounds of a tile per wave instead of two). A cap
+    // that never adds an interior round was tried and is worse at N = 5, 6, 7. BDG_SW2D_INTERIOR_CAP=n pins the cap.
+    int interiorGridCap() const {
+        static const int pinned = [] { const char* e = std::getenv("BDG_SW2D_INTERIOR_CAP"); return e ? std::atoi(e) : 0; }();
+        if (pinned > 0) return pinned;
+        if (N < 5) return kInteriorGridCap;
+        const int stripTiles = (numOwned - numInterior + 15) / 16;
+        return std::max(192, std::min(kInteriorGridCap, 256 - stripTiles));
+    }
 
     void launchRhs(const double* qin, double* out, bool filter) {
         if (filter && !hasFilter) throw arg_error("filter requested but the solver was created without a Filter matrix");
@@ -530,7 +544,7 @@ struct bdg_sw2d {
         bdg_dev::StageParams p = baseParams();
         if (part == 0) {
             p.kend = numInterior;
-            p.gridCap = kInteriorGridCap; // the boundary kernel runs beside this launch (exchange stream)
+            p.gridCap = interiorGridCap(); // the boundary kernel runs beside this launch (exchange stream)
         }
         if (part == 1) p.kbegin = numInterior;
         p.qin = qcur;

@@ -628,7 +628,7 @@ namespace bdg_dev {
 // does its own field's stage update, halo staging included (ghost traces from the received records, new state to the
 // send records). The wave speed of a face needs all three fields, so traces are loaded by all three waves (L1 hits).
 template <int N>
-__global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StageParams p) {
+__global__ __launch_bounds__(192, 2) void sw2d_strip_mfma3_kernel(const StageParams p) {
     using E = Elem<N>;
     using O = MfmaOps2<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF;
@@ -670,11 +670,17 @@ __global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StagePar
             for (int t = 0; t < KV; ++t) qB[i][t] = bld_f64(rq[i], row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
 #pragma unroll
         for (int i = 0; i < 13; ++i) geo[i] = bld_f64(rgeo, k8, static_cast<unsigned>(i) * ld8);
+        auto requestResidual = [&] {
 #pragma unroll
-        for (int t = 0; t < KV; ++t) oldv[t] = bld_f64(rres, row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
+            for (int t = 0; t < KV; ++t) oldv[t] = bld_f64(rres, row_voffset<Np, KV>(t, q, v8), static_cast<unsigned>(4 * t) * ld8);
+        };
+        constexpr bool kLateFace = KV > 9; // N = 8: see requestFace
+        if constexpr (!kLateFace) requestResidual();
         double hM[3][KF], huM[3][KF], hvM[3][KF], hP[3][KF], huP[3][KF], hvP[3][KF];
-#pragma unroll
-        for (int f = 0; f < 3; ++f)
+        // traces of one face: at N <= 7 all three faces are requested up front; at N = 8 (18 doubles per face) the third face
+        // is requested when the first one has been worked on, which keeps the kernel within 256 registers: two workgroups
+        // per CU, so that a strip of 24..47 tiles runs in ONE round on the CUs the interior launch leaves free
+        auto requestFace = [&](int f) {
 #pragma unroll
             for (int tf = 0; tf < KF; ++tf) {
                 const int n = 4 * tf + static_cast<int>(q);
@@ -697,6 +703,12 @@ __global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StagePar
                     hvP[f][tf] = bld_f64(rq[2], o8, 0u);
                 }
             }
+        };
+        requestFace(0);
+        if constexpr (!kLateFace) {
+            requestFace(1);
+            requestFace(2);
+        }
         int sendRec[3] = {-1, -1, -1};
         if (live) {
             const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
@@ -735,6 +747,11 @@ __global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StagePar
             }
         }
 
+        if constexpr (kLateFace) { // the second face and the residual rows behind the first face's work (the other fields' state rows are dead by now)
+            requestFace(1);
+            requestResidual();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- surface term
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
@@ -770,6 +787,12 @@ __global__ __launch_bounds__(192, 1) void sw2d_strip_mfma3_kernel(const StagePar
             }
             lam = fmax(lam, __shfl_xor(lam, 16));
             lam = fmax(lam, __shfl_xor(lam, 32));
+            if constexpr (kLateFace) {
+                if (f == 0) {
+                    requestFace(2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
 #pragma unroll
             for (int tf = 0; tf < KF; ++tf) {
                 const double s = hfs * (e[tf] - lam * d[tf]);
