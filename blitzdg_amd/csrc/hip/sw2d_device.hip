@@ -262,6 +262,7 @@ struct bdg_sw2d {
     bool variantD = false;
     bdg_dev::VdParams vd{};
     DevBuf<double> zxBuf, zyBuf, fcorBuf, opsVd, opsVdFiltered;
+    DevBuf<double> opsVn, filterRows, vnRaw; // variants B / C / D on per-node geometry (sw2d_vn_kernel.hpp)
     // variant B (reference src/sw2d/main.cpp:279-484): depth + star states, open boundary, global LF speed, sources
     bool variantB = false;
     bdg_dev::VbParams vb{};
@@ -354,7 +355,22 @@ struct bdg_sw2d {
         // 250 k elements 136 us vs 109 us -- DESIGN.md section 4).
         int variant = affineVariant;
         if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < kSmallLaunch[N]) variant = 5;
-        if (variantB) {
+        if (!affine && (variantB || variantD)) {
+            // per-node geometry tables: the general (rolled) form of variants B / C / D
+            buildNodalVariantOps();
+            const double* filt = filter ? filterRows.p : nullptr;
+            if (variantB) {
+                vb.tide = tideAt(timeNow);
+                vb.lam = lamBuf.p;
+                vb.lamNext = nullptr;
+                lamStateFor = nullptr;
+                hipCheck(kt->stageVn(mode, 2, p, vd, vb, opsVn.p, filt, vnRaw.p, vbPartials.p, lamBuf.p, !lamExternal, st), what);
+            } else {
+                bdg_dev::VdParams v = vd;
+                v.cbase = 0;
+                hipCheck(kt->stageVn(mode, 1, p, v, vb, opsVn.p, filt, vnRaw.p, nullptr, nullptr, false, st), what);
+            }
+        } else if (variantB) {
             vb.tide = tideAt(timeNow);
             if (lamExternal) {
                 // partitioned run: the global speed of this state was reduced over all ranks into lamBuf beforehand
@@ -800,6 +816,28 @@ struct bdg_sw2d {
         timeNow += dt;
     }
 
+    // Row-wise operator image of the per-node-geometry form of variants B / C / D (VnOps: row i = Dr[i][.], Ds[i][.] interleaved,
+    // then Lift[i][.]), the Filter rows of its second pass and the scratch planes of the unfiltered rows
+    void buildNodalVariantOps() {
+        if (opsVn.p) return;
+        const int row = 2 * Np + NFN;
+        std::vector<double> img(static_cast<size_t>(row) * Np);
+        for (int i = 0; i < Np; ++i) {
+            for (int m = 0; m < Np; ++m) {
+                img[static_cast<size_t>(i) * row + 2 * m] = hostDr[static_cast<size_t>(i) * Np + m];
+                img[static_cast<size_t>(i) * row + 2 * m + 1] = hostDs[static_cast<size_t>(i) * Np + m];
+            }
+            for (int j = 0; j < NFN; ++j) img[static_cast<size_t>(i) * row + 2 * Np + j] = hostLift[static_cast<size_t>(i) * NFN + j];
+        }
+        opsVn.alloc(img.size(), bytes);
+        hipCheck(hipMemcpy(opsVn.p, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice), "nodal variant ops upload");
+        if (!hostFilter.empty()) {
+            filterRows.alloc(hostFilter.size(), bytes);
+            hipCheck(hipMemcpy(filterRows.p, hostFilter.data(), hostFilter.size() * sizeof(double), hipMemcpyHostToDevice), "filter upload");
+            vnRaw.alloc(static_cast<size_t>(nf) * planeSize(), bytes);
+        }
+    }
+
     // [m][i]{Dr'[i][m], Ds'[i][m], F'[i][m]} + Lift' images (F' = I or Filter) for the rolled
     // one-field-per-wave kernels (variants B and D)
     void buildSourceOps() {
@@ -1053,8 +1091,6 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     // Non-affine tables: the matrix-core kernel with per-node geometry (every order). BDG_SW2D_NODAL_VECTOR=1 keeps the
     // round-1 vector kernel (one lane per element, N <= 6) for A/B measurements and cross-checks.
     s->nodalMfma = !s->affine && !(std::getenv("BDG_SW2D_NODAL_VECTOR") && kt->ldsDoubles != 0);
-    if (!s->affine && s->variantD)
-        throw arg_error("bdg_sw2d_create: tracer / source terms are implemented for straight-sided (affine) geometry only");
 
     s->use();
     hipCheck(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -1435,8 +1471,6 @@ int bdg_sw2d_enable_variant_b(bdg_sw2d* s, const bdg_sw2d_vb_desc* d) {
         if (!d || !d->H || !d->Hx || !d->Hy) throw arg_error("bdg_sw2d_enable_variant_b: H, Hx and Hy are required");
         if (s->nf != 3 || s->variantD)
             throw arg_error("bdg_sw2d_enable_variant_b: the solver was created with tracer / variant-D sources");
-        if (!s->affine)
-            throw arg_error("bdg_sw2d_enable_variant_b: implemented for straight-sided (affine) geometry only");
         // partitioned solvers: allowed -- their steppers are the *_exchanged ones, which reduce the global speed over all
         // ranks before each evaluation (evaluateExchanged); the in-process group transport has no such reduction
         if (s->localGroup) throw arg_error("bdg_sw2d_enable_variant_b: not available with the in-process group transport");

@@ -6,6 +6,7 @@
 #include "sw2d_vd_kernel.hpp"
 #include "sw2d_tracer_kernel.hpp"
 #include "sw2d_vb_kernel.hpp"
+#include "sw2d_vn_kernel.hpp"
 #include "sw2d_mfma_kernel.hpp"
 #include "sw2d_mfma3_kernel.hpp"
 #include "sw2d_mfma3src_kernel.hpp"
@@ -54,6 +55,12 @@ struct KernelTable {
     // current); 4: speed pass only; 0: speed pass + rolled kernel with a VdOps image
     hipError_t (*stageVb)(int mode, const StageParams& p, const VbParams& vp, double* partials, double* lam,
                           int unrolled, const double* filterT, hipStream_t stream);
+    // variants B (phys = 2) and C / D (phys = 1) on per-node geometry (sw2d_vn_kernel.hpp): ops = VnOps image; filt != nullptr:
+    // the filtered RHS in two passes (unfiltered rows to raw, nf planes; then Filter and the update); speedPass: variant B's
+    // global speed of this state is reduced into *lam first (else vb.lam is current)
+    int vnOpsDoubles;
+    hipError_t (*stageVn)(int mode, int phys, const StageParams& p, const VdParams& vd, const VbParams& vb, const double* ops,
+                          const double* filt, double* raw, double* partials, double* lam, bool speedPass, hipStream_t stream);
     // per-block partial maxima (2 doubles per block of 256 elements)
     hipError_t (*dt)(const double* q, const double* fscale, const double* H, long long ld, int K, double g,
                      double* partials, hipStream_t stream);

@@ -464,6 +464,46 @@ hipError_t stageVb(int mode, const StageParams& p, const VbParams& vp, double* p
     }
 }
 
+// ---- variants B / C / D on per-node geometry (sw2d_vn_kernel.hpp)
+template <int MODE, int PHYS>
+hipError_t launchVn(const StageParams& p, const VdParams& vd, const VbParams& vb, const double* ops, const double* filt, double* raw,
+                    double* partials, double* lam, bool speedPass, hipStream_t stream) {
+    if (p.kend <= p.kbegin) return hipSuccess;
+    if (PHYS == 2 && speedPass) {
+        const unsigned nblocks = static_cast<unsigned>((p.kend - p.kbegin + 255) / 256);
+        hipLaunchKernelGGL((sw2d_vn_speed_kernel<kN>), dim3(nblocks), dim3(256), 0, stream, p, vb, partials);
+        hipLaunchKernelGGL((sw2d_vb_speed_reduce_kernel<kN>), dim3(1), dim3(256), 0, stream, partials, static_cast<int>(nblocks), lam);
+    }
+    const int nf = PHYS == 2 ? 3 : vd.nf;
+    const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + 63) / 64);
+    if (!filt) {
+        hipLaunchKernelGGL((sw2d_stage_vn_kernel<kN, MODE, PHYS>), dim3(grid), dim3(64 * nf), 0, stream, p, vd, vb, ops);
+    } else {
+        StageParams pr = p;
+        pr.rhs = raw;
+        hipLaunchKernelGGL((sw2d_stage_vn_kernel<kN, MODE_RHS, PHYS>), dim3(grid), dim3(64 * nf), 0, stream, pr, vd, vb, ops);
+        hipLaunchKernelGGL((sw2d_filter_rows_kernel<kN, MODE, PHYS>), dim3(grid), dim3(64 * nf), 0, stream, p, raw, filt, vb.sponge, 0);
+    }
+    return hipGetLastError();
+}
+
+template <int PHYS>
+hipError_t stageVnPhys(int mode, const StageParams& p, const VdParams& vd, const VbParams& vb, const double* ops, const double* filt,
+                       double* raw, double* partials, double* lam, bool speedPass, hipStream_t stream) {
+    switch (mode) {
+    case MODE_RHS: return launchVn<MODE_RHS, PHYS>(p, vd, vb, ops, filt, raw, partials, lam, speedPass, stream);
+    case MODE_LSERK: return launchVn<MODE_LSERK, PHYS>(p, vd, vb, ops, filt, raw, partials, lam, speedPass, stream);
+    case MODE_COMBINE: return launchVn<MODE_COMBINE, PHYS>(p, vd, vb, ops, filt, raw, partials, lam, speedPass, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t stageVn(int mode, int phys, const StageParams& p, const VdParams& vd, const VbParams& vb, const double* ops,
+                   const double* filt, double* raw, double* partials, double* lam, bool speedPass, hipStream_t stream) {
+    return phys == 2 ? stageVnPhys<2>(mode, p, vd, vb, ops, filt, raw, partials, lam, speedPass, stream)
+                     : stageVnPhys<1>(mode, p, vd, vb, ops, filt, raw, partials, lam, speedPass, stream);
+}
+
 hipError_t dt(const double* q, const double* fscale, const double* H, long long ld, int K, double g, double* partials,
               hipStream_t stream) {
     const unsigned grid = static_cast<unsigned>((K + kBlock - 1) / kBlock);
@@ -490,7 +530,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, &stageMfma2Halo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma3Nodal, &stageMfma2Src, kMfma3SrcFields, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, &dt, &output,
+                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma3Nodal, &stageMfma2Src, kMfma3SrcFields, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, VnOps<kN>::DOUBLES, &stageVn, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

@@ -23,6 +23,7 @@ Writes
                             hN = 0, f = CD = 0, zx = zy = 0  (variant D == variant A up
                             to round-off)
   sw2d_rhs4_<case>.npz      the same function with tracer, Coriolis array, drag and bed slope
+  sw2d_rhs4n_<case>.npz     the same on per-node (non-affine) rx .. sy, nx, ny, Fscale of a smoothly deformed mesh
   sw2d_rhs_curved_<case>.npz
                             swhelpers.rhs.sw2dComputeRHS_curved (swhelpers/rhs.py:6-176) on deformed
                             meshes; the Gauss-face and cubature contexts it reads are built by THIS
@@ -131,9 +132,33 @@ def rhs_case(name, mesh, order, g=9.81):
           f"{max(abs(r1).max(), abs(r2).max(), abs(r3).max()):.6g}")
 
 
-def rhs4_case(name, mesh, order, g=9.81):
+def deformed_tables(ctx, order, tabs):
+    """Per-node metric terms and face geometry of a smoothly deformed mesh by the reference's formulas
+    (src/TriangleNodesProvisioner.cpp:810-892) from this repository's Dr / Ds: genuinely non-affine rx .. Fscale."""
+    x0, y0 = ctx.x, ctx.y
+    x = x0 + 0.06 * np.sin(2.1 * y0) * (1 - x0 * x0)
+    y = y0 + 0.05 * np.sin(2.7 * x0 + 0.3) * (1 - y0 * y0)
+    Dr, Ds = ctx.Dr, ctx.Ds
+    xr, xs, yr, ys = Dr @ x, Ds @ x, Dr @ y, Ds @ y
+    J = xr * ys - xs * yr
+    assert J.min() > 0
+    tabs.update(rx=ys / J, sx=-yr / J, ry=-xs / J, sy=xr / J, x=x, y=y)
+    Nfp = order + 1
+    Fm = ctx.Fmask.T.reshape(-1) if ctx.Fmask.shape[0] == Nfp else ctx.Fmask.reshape(-1)
+    fxr, fxs, fyr, fys = xr[Fm], xs[Fm], yr[Fm], ys[Fm]
+    nxf, nyf = np.empty_like(fxr), np.empty_like(fxr)
+    nxf[:Nfp], nyf[:Nfp] = fyr[:Nfp], -fxr[:Nfp]
+    nxf[Nfp:2 * Nfp], nyf[Nfp:2 * Nfp] = fys[Nfp:2 * Nfp] - fyr[Nfp:2 * Nfp], -fxs[Nfp:2 * Nfp] + fxr[Nfp:2 * Nfp]
+    nxf[2 * Nfp:], nyf[2 * Nfp:] = -fys[2 * Nfp:], fxs[2 * Nfp:]
+    sJ = np.hypot(nxf, nyf)
+    tabs.update(nx=nxf / sJ, ny=nyf / sJ, Fscale=sJ / J[Fm])
+    return tabs
+
+
+def rhs4_case(name, mesh, order, g=9.81, deformed=False):
     """Variant D: tracer + Coriolis (array f) + drag + bed slope, all non-trivial; output of the
-    reference's swhelpers.rhs.sw2dComputeRHS itself."""
+    reference's swhelpers.rhs.sw2dComputeRHS itself. deformed: on the per-node geometry tables of a smoothly deformed
+    mesh (sw2d_rhs4n_<case>.npz) -- the function takes whatever rx .. Fscale the context holds."""
     import blitzdg_amd.pyblitzdg as dg
     sys.path.insert(0, REF)
     if not hasattr(np, "float"):
@@ -148,6 +173,8 @@ def rhs4_case(name, mesh, order, g=9.81):
     tabs["Filter"] = ctx.filter
     bcmap = ctx.BCmap
     tabs["mapW"] = np.array(bcmap.get(3, []), dtype=np.int32)
+    if deformed:
+        deformed_tables(ctx, order, tabs)
     x, y = tabs["x"], tabs["y"]
     h, hu, hv = seeded_fields(x, y)
     rng = np.random.default_rng(1)
@@ -161,9 +188,10 @@ def rhs4_case(name, mesh, order, g=9.81):
                                     numFacePoints=ctx.numFacePoints, numElements=ctx.numElements,
                                     numFaces=ctx.numFaces, Lift=tabs["Lift"], Fscale=tabs["Fscale"])
     r = sw2dComputeRHS(h, hu, hv, hN, zx, zy, g, H, f, CD, ref_ctx, tabs["vmapM"], tabs["vmapP"])
-    np.savez_compressed(os.path.join(HERE, f"sw2d_rhs4_{name}.npz"), order=order, g=g, h=h, hu=hu, hv=hv, hN=hN,
+    stem = "sw2d_rhs4n" if deformed else "sw2d_rhs4"
+    np.savez_compressed(os.path.join(HERE, f"{stem}_{name}.npz"), order=order, g=g, h=h, hu=hu, hv=hv, hN=hN,
                         H=H, zx=zx, zy=zy, f=f, CD=CD, rhs1=r[0], rhs2=r[1], rhs3=r[2], rhs4=r[3], **tabs)
-    print(f"sw2d_rhs4_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} |rhs|max="
+    print(f"{stem}_{name}.npz: K={ctx.numElements} Np={ctx.numLocalPoints} |rhs|max="
           f"{max(abs(a).max() for a in r):.6g}")
 
 
@@ -411,6 +439,15 @@ def main():
     advec1d_case()
     curved_cases()
     degenerate_b_cases()
+    nodal_cases()
+
+
+def nodal_cases():
+    import blitzdg_amd.pyblitzdg as dg
+    for order, (nx, ny) in ((2, (7, 6)), (4, (6, 5)), (6, (5, 4)), (8, (3, 2))):
+        mesh = dg.MeshManager()
+        mesh.buildBoxMesh(nx, ny, shuffleSeed=77)
+        rhs4_case(f"box{nx}x{ny}_N{order}", mesh, order, deformed=True)
 
 
 def degenerate_b_cases():
@@ -452,6 +489,8 @@ if __name__ == "__main__":
         curved_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "variant_b":
         degenerate_b_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "nodal":
+        nodal_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "degenerate_b":
         degenerate_b_cases()
     else:

@@ -236,6 +236,21 @@ def test_variant_b_oracle_reproduces_the_reference_over_a_continuous_bed(case, t
         assert np.abs(r0[1] - d["rhs2"]).max() / scale > 1e-7
 
 
+@pytest.mark.parametrize("case", ["box7x6_N2", "box6x5_N4", "box5x4_N6", "box3x2_N8"])
+def test_variant_d_oracle_reproduces_the_reference_on_per_node_geometry(case):
+    """The reference function on genuinely non-affine tables (metric terms and normals of a smoothly deformed mesh per
+    node; tests/golden/sw2d_rhs4n_*.npz, make_golden.py::rhs4_case(deformed=True)): the NumPy restatement, which
+    performs the same operations in the same order, reproduces its output bit for bit."""
+    import os
+    from conftest import GOLDEN
+    from oracle.oracle_np import sw2d_rhs4
+    d = np.load(os.path.join(GOLDEN, f"sw2d_rhs4n_{case}.npz"))
+    assert np.ptp(d["rx"], axis=0).max() > 1e-3                 # the metric does vary inside the elements
+    r = sw2d_rhs4(d["h"], d["hu"], d["hv"], d["hN"], d["zx"], d["zy"], float(d["g"]), d["f"], float(d["CD"]), d)
+    for c in range(4):
+        assert np.array_equal(r[c], d[f"rhs{c + 1}"])
+
+
 def test_variant_b_sources_agree_with_variant_d_fixture():
     """Bed slope and Coriolis of variant B (RHS2 += g h Hx + f hv, RHS3 += g h Hy - f hu) are variant
     D's with zx = -Hx, zy = -Hy (drag differs by D's sign quirk, so CD = 0 here); the tracer is ignored."""
