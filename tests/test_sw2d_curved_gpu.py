@@ -219,6 +219,29 @@ def test_contexts_without_face_structure_fall_back_to_the_general_form(form):
         assert relerr(ref, [d[f"rhs{i}"] for i in (1, 2, 3, 4)]) > 1e-6      # the rewiring does change the answer
 
 
+def test_curved_driver_example_runs_the_reference_loop(form):
+    """examples/sw2d_curved.py = the reference's sw2d_curved.py driver (curved wall, periodic ends, wall-layer drag, tracer,
+    RK2 + filter) on this repository's API: 40 steps stay finite, the periodic rewiring keeps the nodal-trace kernels,
+    the tracer stays within its initial bounds to the filter's overshoot, mass drifts by round-off times steps only."""
+    import re
+    import sys
+
+    from conftest import ROOT, launch
+    env = dict(os.environ)
+    if form == "general":
+        env["BDG_SW2D_CURVED_GENERAL"] = "1"
+    else:
+        env.pop("BDG_SW2D_CURVED_GENERAL", None)
+    out = launch([sys.executable, os.path.join(ROOT, "examples", "sw2d_curved.py"), "box:12x8", "3", "40"], env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "done: steps=40" in out.stdout
+    assert f"nodal-trace kernels={form == 'nodal-trace'}" in out.stdout
+    drift = float(re.findall(r"mass drift=([-+.\deE]+)", out.stdout)[-1])
+    assert abs(drift) < 1e-9
+    lo, hi = (float(v) for v in re.findall(r"N in \[([-+.\deE]+), ([-+.\deE]+)\]", out.stdout)[-1])
+    assert -0.05 < lo and hi < 1.05
+
+
 def test_bad_tables_are_refused_before_anything_runs():
     d = np.load(CURVED[0])
     ctx, cub, gauss = contexts_from_fixture(d)
