@@ -158,13 +158,34 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
     __builtin_amdgcn_sched_barrier(0);
     // ---- neighbour ('+') traces: gathers from the same planes, served by L1/L2
     double hP[NFN], huP[NFN], hvP[NFN], hNP[TRACER ? NFN : 1];
+    auto gatherFace = [&](int f) {
 #pragma unroll
-    for (int j = 0; j < NFN; ++j) {
-        const unsigned o8 = static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u;
-        hP[j] = ld_row(qin, o8);
-        huP[j] = ld_row(qin + plane, o8);
-        hvP[j] = ld_row(qin + 2 * plane, o8);
-        if constexpr (TRACER) hNP[j] = ld_row(qin + 3 * plane, o8);
+        for (int n = 0; n < Nfp; ++n) {
+            const int j = f * Nfp + n;
+            const unsigned o8 = static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u;
+            hP[j] = ld_row(qin, o8);
+            huP[j] = ld_row(qin + plane, o8);
+            hvP[j] = ld_row(qin + 2 * plane, o8);
+            if constexpr (TRACER) hNP[j] = ld_row(qin + 3 * plane, o8);
+        }
+    };
+    // Three fields: all three faces' traces in one batch. With the tracer (4 x 3 Nfp traces beside 4 Np state values and 4 Np
+    // accumulators) the third face is requested when the first has been worked on: 28-55 spilled registers otherwise.
+    // (the LSERK form keeps the single batch and its residual rows in the early batch: with the late requests it came out
+    // at 40-60 spilled registers instead of 28, and 5 % slower)
+    constexpr bool kLateFace = TRACER && MODE != MODE_LSERK;
+    if constexpr (kLateFace) {
+        gatherFace(0);
+        gatherFace(1);
+    } else { // (the loop as it always was: the register allocation of these kernels is sensitive to the very order of requests)
+#pragma unroll
+        for (int j = 0; j < NFN; ++j) {
+            const unsigned o8 = static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u;
+            hP[j] = ld_row(qin, o8);
+            huP[j] = ld_row(qin + plane, o8);
+            hvP[j] = ld_row(qin + 2 * plane, o8);
+            if constexpr (TRACER) hNP[j] = ld_row(qin + 3 * plane, o8);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -239,6 +260,12 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
                 if constexpr (TRACER) R4[i] = fma(lj, s4, R4[i]);
             }
         }
+        if constexpr (kLateFace) {
+            if (f == 0) {
+                gatherFace(2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     }
 
     // ---- stage inputs that are only needed at the very end: issue now, land during the volume loop
@@ -259,9 +286,9 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             old1[i] = ld_row(qb + i * ld, k8);
             old2[i] = ld_row(qb + plane + i * ld, k8);
             old3[i] = ld_row(qb + 2 * plane + i * ld, k8);
-            if constexpr (TRACER) old4[i] = ld_row(qb + 3 * plane + i * ld, k8);
         }
     }
+    // (combine steps: the tracer's base rows are requested after the volume loop)
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- volume term, one input node at a time:
@@ -322,6 +349,12 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
         if constexpr (TRACER) applyFilter(R4);
     }
 
+    if constexpr (TRACER && MODE == MODE_COMBINE) {
+        const double* __restrict__ o4 = p.qbase + 3 * plane;
+#pragma unroll
+        for (int i = 0; i < Np; ++i) old4[i] = ld_row(o4 + i * ld, k8);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- stage update / output
     if constexpr (MODE == MODE_RHS) {
         double* __restrict__ o = p.rhs;
@@ -369,7 +402,10 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             st_row(o + i * ld, k8, a * old1[i] + b * h[i] + c * R1[i]);
             st_row(o + plane + i * ld, k8, SPONGE ? v2 / (1.0 + sg * v2 * v2) : v2);
             st_row(o + 2 * plane + i * ld, k8, SPONGE ? v3 / (1.0 + sg * v3 * v3) : v3);
-            if constexpr (TRACER) st_row(o + 3 * plane + i * ld, k8, a * old4[i] + b * hN[i] + c * R4[i]);
+        }
+        if constexpr (TRACER) {
+#pragma unroll
+            for (int i = 0; i < Np; ++i) st_row(o + 3 * plane + i * ld, k8, a * old4[i] + b * hN[i] + c * R4[i]);
         }
     }
 }
