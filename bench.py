@@ -62,13 +62,16 @@ def strip_comments(text):
 
 
 def kernel_source_sha():
-    """Hash of the device sources WITHOUT their comments and layout: a committed PMC summary is only quoted while it
+    """Hash of the device sources of the straight-element kernels (everything under csrc/hip but sw2d_curved_*) WITHOUT their
+    comments and layout: a committed PMC summary is only quoted while it
     still describes the kernels that are being timed (profiles/summarize.py records the same hash), and a comment or
     re-indentation does not invalidate a collection (in round 2 a header comment cost a full PMC run)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "blitzdg_amd", "csrc", "hip", "*"))):
+        if os.path.basename(f).startswith("sw2d_curved"):
+            continue        # the curved solver's own translation units: not part of what this benchmark times
         h.update(os.path.basename(f).encode())
         h.update(strip_comments(open(f, errors="replace").read()).encode())
     return h.hexdigest()[:16]
