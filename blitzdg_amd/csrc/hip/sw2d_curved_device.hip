@@ -128,6 +128,8 @@ struct bdg_sw2d_curved {
         if (useNT) {
             p.opsNT = opsNT.p; p.nodeP = nodeP.p; p.faceFlags = faceFlags.p; p.gaussWref = gaussWref.p;
             p.affineEl = nullptr; p.elAffine = elAffine.p; // (the straight-element flag rides in faceFlags)
+            static const int interleave = [] { const char* e = std::getenv("BDG_SW2D_TILE_INTERLEAVE"); return e ? std::atoi(e) : 1; }();
+            p.tileInterleave = interleave;
         }
         return p;
     }

@@ -75,6 +75,7 @@ struct CurvedParams {
     const int* faceFlags;    // ld: bit f set = face f is a wall; bit 3: straight element (elAffine holds its numbers)
     const double* elAffine;  // (14, ld), zeros on other elements: straight elements: W rx, W ry, W sx, W sy factors; nx, ny, W factor per face; 1 / J
     const double* gaussWref; // 16 fb: HALF the Gauss weights of a reference straight face (zero padded)
+    int tileInterleave;      // 1: the waves of an XCD take its tiles side by side (default); 0: a contiguous run per wave
     const double* filt;   // (Np, Np) row-major filter for the fix-up kernel, or nullptr
     long long ld;
     int K;

@@ -124,15 +124,31 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                    soFc = p.fcor ? static_cast<unsigned>((p.fcor - p.rJ) * 8) : 0u, soCd = p.cd ? static_cast<unsigned>((p.cd - p.rJ) * 8) : 0u;
     const double g = p.g;
     const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u;
-    unsigned tile, tileEnd;
-    curved_wave_tiles(ntiles, tile, tileEnd);
-    // lockstep form: every wave of the workgroup makes the same number of passes (a wave without a tile only keeps the
-    // barriers and the chunk copies company)
-    const unsigned nwavesAll = gridDim.x * (blockDim.x >> 6);
-    const unsigned passes = STREAM ? (ntiles + nwavesAll - 1u) / nwavesAll : (tileEnd > tile ? tileEnd - tile : 0u);
+    // Tiles of this wave. XCD x (workgroups b with b mod 8 = x share its L2) owns one contiguous eighth of the tiles; its waves
+    // take them SIDE BY SIDE (wave w of W: tiles w, w + W, ...), so that what an XCD holds at any time is a compact patch of
+    // the mesh and the neighbours' face nodes a tile gathers are rows a sibling wave is streaming (p.tileInterleave = 0: one
+    // contiguous run of tiles per wave, as in the first form). Every wave of an XCD makes the same number of passes (the
+    // lockstep form needs that of a workgroup's waves: a wave without a tile keeps the barriers and the chunk copies company).
+    unsigned tile, tileEnd, tileStep, passes;
+    if (p.tileInterleave) {
+        const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, wgHere = nwg / 8u + (xcd < nwg % 8u ? 1u : 0u);
+        const unsigned nx = nwg < 8u ? nwg : 8u; // XCDs that have a workgroup of this launch
+        const unsigned t0 = static_cast<unsigned>((static_cast<unsigned long long>(ntiles) * xcd) / nx),
+                       t1 = static_cast<unsigned>((static_cast<unsigned long long>(ntiles) * (xcd + 1u)) / nx);
+        const unsigned wavesHere = wgHere * (blockDim.x >> 6), w = (blockIdx.x / 8u) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        tile = t0 + w;
+        tileEnd = t1;
+        tileStep = wavesHere;
+        passes = (t1 - t0 + wavesHere - 1u) / wavesHere;
+    } else {
+        curved_wave_tiles(ntiles, tile, tileEnd);
+        const unsigned nwavesAll = gridDim.x * (blockDim.x >> 6);
+        tileStep = 1u;
+        passes = STREAM ? (ntiles + nwavesAll - 1u) / nwavesAll : (tileEnd > tile ? tileEnd - tile : 0u);
+    }
     int phase = 0; // stream buffer that holds the chunk about to be used
 
-    for (unsigned pass = 0; pass < passes; ++pass, ++tile) {
+    for (unsigned pass = 0; pass < passes; ++pass, tile += tileStep) {
         const bool act = tile < tileEnd;
         const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
         const bool live = act && kTrue <= kLast;
