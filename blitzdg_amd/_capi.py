@@ -11,6 +11,9 @@ from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_in
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# Sharing device memory between rank processes (RCCL's intra-node transport) needs the dmabuf IPC mode on this driver stack; the
+# runtime reads the variable when it initialises, which is after this module is imported. A caller's own setting wins.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # BDG_HIP_LIBRARY: another build of the same library (profiling builds under build/); there is still no fallback
 LIB_PATH = os.environ.get("BDG_HIP_LIBRARY") or os.path.join(_HERE, "lib", "libblitzdg_hip.so")
 
