@@ -214,6 +214,9 @@ _SIGNATURES = {
     "bdg_sw2d_curved_device_bytes": (c_size_t, [_P]),
     "bdg_sw2d_curved_bytes_per_element": (c_double, [_P]),
     "bdg_sw2d_curved_form": (c_int, [_P]),
+    "bdg_sw2d_curved_get_elements": (c_int, [_P, c_int, c_int, c_int, POINTER(c_double)]),
+    "bdg_sw2d_curved_set_elements": (c_int, [_P, c_int, c_int, c_int, POINTER(c_double)]),
+    "bdg_sw2d_curved_rk2_phase": (c_int, [_P, c_double, c_int, c_int]),
 }
 
 #: every symbol include/blitzdg_hip.h declares (checked by tests/test_capi_symbols.py)

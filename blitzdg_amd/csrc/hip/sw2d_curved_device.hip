@@ -709,6 +709,10 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
                                 (d.zy ? Np : 0) + (d.coriolis ? Np : 0) + (d.drag ? Np : 0) + 4 * Np +
                                 (identityM ? 2 : 3) * 4 * NG3) +
                          4.0 * (NG3 * (identityM ? 1 : 2) + 2);
+    if (s->useNT) { // the Gauss-trace planes and maps belong to the general form only
+        for (Buf<double>* b : {&s->gq}) { s->bytes -= b->n * sizeof(double); b->release(); }
+        for (Buf<int>* b : {&s->gmapP, &s->gmapM}) { s->bytes -= b->n * sizeof(int); b->release(); }
+    }
     if (s->useNT) { // state in, update in / out, the neighbours' face nodes, node map + flags, geometry (14 numbers on straight elements), sources
         const double fa = static_cast<double>(s->numAffineNT) / K;
         const int Nfp = s->N + 1, KE = (Nfp + 3) / 4;
@@ -810,6 +814,49 @@ int bdg_sw2d_curved_time_rk2(bdg_sw2d_curved* s, double dt, int num_steps, int f
         float ms = 0.f;
         hipOk(hipEventElapsedTime(&ms, s->ev0, s->ev1), "hipEventElapsedTime");
         *ms_per_rhs = ms / (2.0f * static_cast<float>(num_steps));
+    });
+}
+
+namespace {
+double* curvedBuffer(bdg_sw2d_curved* s, int which, int first, int count, const char* fn) {
+    requireCurved(s, fn);
+    if (which != 0 && which != 1) throw arg_error(std::string(fn) + ": which must be 0 (state) or 1 (intermediate)");
+    if (first < 0 || count < 0 || static_cast<long long>(first) + count > s->K) throw arg_error(std::string(fn) + ": element range out of bounds");
+    return (which == 0 ? s->qA.p : s->qB.p) + first;
+}
+} // namespace
+
+int bdg_sw2d_curved_get_elements(bdg_sw2d_curved* s, int which, int first, int count, double* out) {
+    return guard([&] {
+        const double* dev = curvedBuffer(s, which, first, count, "bdg_sw2d_curved_get_elements");
+        if (count == 0) return;
+        if (!out) throw arg_error("bdg_sw2d_curved_get_elements: NULL buffer");
+        s->use();
+        hipOk(hipMemcpy2DAsync(out, static_cast<size_t>(count) * sizeof(double), dev, static_cast<size_t>(s->ld) * sizeof(double),
+                               static_cast<size_t>(count) * sizeof(double), static_cast<size_t>(4) * s->Np, hipMemcpyDeviceToHost, s->stream), "D2H copy");
+        hipOk(hipStreamSynchronize(s->stream), "download sync");
+    });
+}
+
+int bdg_sw2d_curved_set_elements(bdg_sw2d_curved* s, int which, int first, int count, const double* in) {
+    return guard([&] {
+        double* dev = curvedBuffer(s, which, first, count, "bdg_sw2d_curved_set_elements");
+        if (count == 0) return;
+        if (!in) throw arg_error("bdg_sw2d_curved_set_elements: NULL buffer");
+        s->use();
+        hipOk(hipMemcpy2DAsync(dev, static_cast<size_t>(s->ld) * sizeof(double), in, static_cast<size_t>(count) * sizeof(double),
+                               static_cast<size_t>(count) * sizeof(double), static_cast<size_t>(4) * s->Np, hipMemcpyHostToDevice, s->stream), "H2D copy");
+        hipOk(hipStreamSynchronize(s->stream), "upload sync");
+    });
+}
+
+int bdg_sw2d_curved_rk2_phase(bdg_sw2d_curved* s, double dt, int phase, int filter) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_rk2_phase");
+        if (phase != 0 && phase != 1) throw arg_error("bdg_sw2d_curved_rk2_phase: phase must be 0 (predictor) or 1 (corrector)");
+        s->use();
+        if (phase == 0) s->evaluate(bdg_dev::CMODE_COMBINE, filter != 0, s->qA.p, s->qA.p, s->qB.p, 1.0, 0.0, 0.5 * dt);
+        else s->evaluate(bdg_dev::CMODE_COMBINE, filter != 0, s->qB.p, s->qA.p, s->qA.p, 1.0, 0.0, dt);
     });
 }
 

@@ -14,7 +14,7 @@ There is no CPU fallback: without the HIP library / a GPU, construction raises.
 import numpy as np
 
 from . import _capi as C
-from ._capi import byref, c_float, c_void_p, check, lib
+from ._capi import POINTER, byref, c_double, c_float, c_void_p, check, lib
 
 
 class Sw2dCurvedSolver:
@@ -124,6 +124,96 @@ class Sw2dCurvedSolver:
     def synchronize(self):
         check(lib.bdg_sw2d_curved_synchronize(self._h))
 
+    # ---- element-partitioned runs: ghost columns in and out, the two halves of a step
+    def getElements(self, first, count, intermediate=False):
+        """Columns [first, first + count) of the resident state (or of the RK2 intermediate state) as a (4 Np, count) array."""
+        out = np.empty((4 * self.Np, int(count)))
+        check(lib.bdg_sw2d_curved_get_elements(self._h, int(bool(intermediate)), int(first), int(count),
+                                               out.ctypes.data_as(POINTER(c_double))))
+        return out
+
+    def setElements(self, first, values, intermediate=False):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        if v.ndim != 2 or v.shape[0] != 4 * self.Np:
+            raise ValueError(f"expected a (4 Np = {4 * self.Np}, count) array")
+        check(lib.bdg_sw2d_curved_set_elements(self._h, int(bool(intermediate)), int(first), v.shape[1],
+                                               v.ctypes.data_as(POINTER(c_double))))
+
+    def rk2Phase(self, dt, phase, filter=True):
+        """phase 0: intermediate = state + dt/2 RHS(state); phase 1: state += dt RHS(intermediate)."""
+        check(lib.bdg_sw2d_curved_rk2_phase(self._h, float(dt), int(phase), int(bool(filter))))
+
     deviceBytes = property(lambda self: lib.bdg_sw2d_curved_device_bytes(self._h))
     bytesPerElement = property(lambda self: lib.bdg_sw2d_curved_bytes_per_element(self._h))
     usesNodalTraces = property(lambda self: lib.bdg_sw2d_curved_form(self._h) == 1)
+
+
+class DistributedSw2dCurved:
+    """The curved / over-integrated solver on an element partition, one process per rank (no reference analogue: the reference is
+    single-process). Each rank holds its owned elements plus one layer of ghost elements of the mesh (``halo.build_plan``); the
+    contexts are built by the provisioner on that local mesh from the caller's deformation of the node coordinates, and before
+    EVERY RHS evaluation the ghost columns of the state that evaluation reads are refreshed from their owners over
+    ``torch.distributed`` (gloo: host tensors; nccl = RCCL: device tensors). Ghost elements are computed like any other (their
+    outer faces are walls of the local mesh) and their results are discarded -- overwritten by the next exchange.
+
+    A functional path (host-staged columns, no overlap with the interior elements); the overlapped, RCCL-native schedule of the
+    straight-element solver (halo.NativeDistributedSw2d) has no curved counterpart yet."""
+
+    def __init__(self, plan, order, deform, dist, g=9.81, filter_args=None, sources=None, device=0):
+        """deform(x0, y0) -> (x, y): node coordinates of the curved mesh from the straight ones (elements it moves are listed in
+        curvedEls); sources(x, y) -> dict with any of zx, zy, f, CD (arrays or scalars)."""
+        from . import pyblitzdg as dg
+        from .halo import build_local_mesh
+        self.plan, self.dist, self.order = plan, dist, order
+        mesh = build_local_mesh(plan)
+        nodes = dg.TriangleNodesProvisioner(order, mesh)
+        if filter_args is not None:
+            nodes.buildFilter(*filter_args)
+        ctx = nodes.dgContext()
+        x0, y0 = ctx.x, ctx.y
+        x, y = deform(x0, y0)
+        curved = np.where((np.abs(x - x0) + np.abs(y - y0)).max(axis=0) > 0)[0]
+        nodes.setCoordinates(x, y)
+        J = (ctx.Dr @ x) * (ctx.Ds @ y) - (ctx.Ds @ x) * (ctx.Dr @ y)
+        gauss = nodes.buildGaussFaceNodes(2 * (order + 1))
+        cub = nodes.buildCubatureVolumeMesh(3 * (order + 1))
+        src = sources(x, y) if sources else {}
+        self.solver = Sw2dCurvedSolver(ctx, cub, gauss, curved, J, gauss.mapM, gauss.mapP, g=g, zx=src.get("zx"), zy=src.get("zy"),
+                                       f=src.get("f", 0.0), CD=src.get("CD", 0.0), device=device)
+        self.nodes, self.ctx, self.cub, self.x, self.y = nodes, ctx, cub, x, y
+        self.filtered = filter_args is not None
+        self._torch = __import__("torch")
+        self._on_device = dist.get_backend() == "nccl"
+
+    def set_initial_state(self, fn):
+        self.solver.setState(*fn(self.x, self.y))
+
+    def _exchange(self, intermediate):
+        """Ghost columns of the state the next evaluation reads, from their owners."""
+        plan, torch, dist = self.plan, self._torch, self.dist
+        n_own, n_int = plan.num_owned, plan.num_interior
+        rows = 4 * self.solver.Np
+        boundary = self.solver.getElements(n_int, n_own - n_int, intermediate)          # the partition-boundary block
+        send = np.ascontiguousarray(boundary[:, plan.send_local - n_int].T)               # (n_send, rows): one record per element
+        dev = torch.device("cuda", 0) if self._on_device else torch.device("cpu")
+        sendbuf = torch.from_numpy(send).to(dev)
+        recvbuf = torch.zeros((max(plan.num_halo, 1), rows), dtype=torch.float64, device=dev)
+        from .halo import exchange_ops
+        ops = exchange_ops(plan, sendbuf, recvbuf, dist)
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if plan.num_halo:
+            self.solver.setElements(n_own, recvbuf[:plan.num_halo].cpu().numpy().T, intermediate)
+
+    def step_rk2(self, dt, nsteps=1):
+        """The driver's loop body (sw2d_curved.py:246-277) with an exchange in front of each of its two evaluations."""
+        for _ in range(nsteps):
+            self._exchange(False)
+            self.solver.rk2Phase(dt, 0, self.filtered)
+            self._exchange(True)
+            self.solver.rk2Phase(dt, 1, self.filtered)
+
+    def owned_state(self):
+        n = self.plan.num_owned
+        return (self.plan.own_global,) + tuple(a[:, :n] for a in self.solver.getState())

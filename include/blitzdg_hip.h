@@ -457,6 +457,15 @@ int bdg_sw2d_curved_lserk4_stages(bdg_sw2d_curved* s, double dt, int num_stages)
  * (Gauss-trace kernel + stage kernel + curved-element kernel), two evaluations per step. */
 int bdg_sw2d_curved_time_rk2(bdg_sw2d_curved* s, double dt, int num_steps, int filter, float* ms_per_rhs);
 int bdg_sw2d_curved_synchronize(bdg_sw2d_curved* s);
+/* Element-partitioned runs (blitzdg_amd.sw2d_curved.DistributedSw2dCurved; no reference analogue, the reference is
+ * single-process): the solver is created on a rank-local mesh [owned elements | ghost elements], and the caller refreshes the
+ * ghost columns before every RHS evaluation. Columns [first, first + count) of all 4 Np rows of the resident state
+ * (which = 0) or of the RK2 intermediate state (which = 1), as a (4 Np, count) row-major host array: */
+int bdg_sw2d_curved_get_elements(bdg_sw2d_curved* s, int which, int first, int count, double* out);
+int bdg_sw2d_curved_set_elements(bdg_sw2d_curved* s, int which, int first, int count, const double* in);
+/* One half of the driver's step (sw2d_curved.py:246-277), so that a ghost exchange fits between the two evaluations:
+ * phase 0 -- predictor, intermediate = state + dt/2 RHS(state); phase 1 -- corrector, state += dt RHS(intermediate). */
+int bdg_sw2d_curved_rk2_phase(bdg_sw2d_curved* s, double dt, int phase, int filter);
 size_t bdg_sw2d_curved_device_bytes(const bdg_sw2d_curved* s);
 /* Compulsory HBM bytes of one RHS evaluation with the tables as this solver holds them (per element, averaged). */
 double bdg_sw2d_curved_bytes_per_element(const bdg_sw2d_curved* s);

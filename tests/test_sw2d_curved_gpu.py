@@ -242,6 +242,87 @@ def test_curved_driver_example_runs_the_reference_loop(form):
     assert -0.05 < lo and hi < 1.05
 
 
+# ---- element-partitioned curved solver: one process per rank on this one GPU, ghost columns over gloo
+
+DIST_MESH, DIST_ORDER, DIST_STEPS, DIST_DT = (14, 10), 3, 4, 2e-3
+
+
+def _dist_deform(x0, y0):
+    blend = np.clip(1.0 - (y0 + 1.0) / 0.35, 0.0, 1.0) ** 3
+    return x0 + 0.01 * blend * np.sin(2 * y0 + 1), y0 + 0.04 * blend * np.sin(np.pi * x0)
+
+
+def _dist_state(x, y):
+    h = 1.0 + 0.3 * np.exp(-6 * x * x - 6 * (y + 0.3) ** 2)
+    return h, 0.05 * np.sin(3 * x + 1) * np.cos(2 * y), 0.05 * np.cos(2 * x) * np.sin(3 * y - 1), h * (0.5 + 0.3 * np.sin(2 * x) * np.cos(3 * y))
+
+
+def _dist_sources(x, y):
+    return {"zx": 0.05 + 0 * x, "zy": -0.04 * y, "f": 0.0788, "CD": 2.5e-3 * (1.0 + 0.5 * np.cos(x))}
+
+
+def _curved_rank_worker(rank, world, port, out_dir, general):
+    import sys
+    import torch.distributed as dist
+    from blitzdg_amd.halo import build_plan
+    from blitzdg_amd.sw2d_curved import DistributedSw2dCurved
+    if general:
+        os.environ["BDG_SW2D_CURVED_GENERAL"] = "1"
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        mesh = dg.MeshManager()
+        mesh.buildBoxMesh(*DIST_MESH, shuffleSeed=5)
+        mesh.partitionMesh(world)
+        plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, rank, world, bctype=mesh.bcType)
+        d = DistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, dist, g=0.0245, filter_args=(0.9 * DIST_ORDER, DIST_ORDER),
+                                  sources=_dist_sources)
+        d.set_initial_state(_dist_state)
+        d.step_rk2(DIST_DT, DIST_STEPS)
+        out = d.owned_state()
+        np.savez(os.path.join(out_dir, f"curved{rank}.npz"), ids=out[0], ghosts=plan.num_halo, **{f"q{i}": a for i, a in enumerate(out[1:])})
+    finally:
+        dist.destroy_process_group()
+    sys.stdout.flush()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world, form):
+    """DistributedSw2dCurved: each rank owns a part of a deformed, shuffled box mesh plus a ghost layer, refreshes the ghost
+    columns before every RHS evaluation (gloo) and runs the driver's RK2 + filter steps; the owned states equal the
+    single-domain solver's to round-off (the tiling of the elements differs between the runs, so not bit for bit)."""
+    import socket
+    from conftest import launch_ranks
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    launch_ranks("test_sw2d_curved_gpu", "_curved_rank_worker", world, (world, port, str(tmp_path), form == "general"))
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*DIST_MESH, shuffleSeed=5)
+    nodes = dg.TriangleNodesProvisioner(DIST_ORDER, mesh)
+    nodes.buildFilter(0.9 * DIST_ORDER, DIST_ORDER)
+    ctx = nodes.dgContext()
+    x, y = _dist_deform(ctx.x, ctx.y)
+    curved = np.where((np.abs(x - ctx.x) + np.abs(y - ctx.y)).max(axis=0) > 0)[0]
+    nodes.setCoordinates(x, y)
+    J = (ctx.Dr @ x) * (ctx.Ds @ y) - (ctx.Ds @ x) * (ctx.Dr @ y)
+    gauss, cub = nodes.buildGaussFaceNodes(2 * (DIST_ORDER + 1)), nodes.buildCubatureVolumeMesh(3 * (DIST_ORDER + 1))
+    src = _dist_sources(x, y)
+    s = Sw2dCurvedSolver(ctx, cub, gauss, curved, J, gauss.mapM, gauss.mapP, g=0.0245, zx=src["zx"], zy=src["zy"], f=src["f"], CD=src["CD"])
+    q0 = _dist_state(x, y)
+    s.setState(*q0)
+    s.stepRK2(DIST_DT, DIST_STEPS, filter=True)
+    ref = s.getState()
+    seen = np.zeros(mesh.numElements, dtype=int)
+    for r in range(world):
+        p = np.load(tmp_path / f"curved{r}.npz")
+        seen[p["ids"]] += 1
+        assert int(p["ghosts"]) > 0
+        for i, full in enumerate(ref):
+            assert np.abs(p[f"q{i}"] - full[:, p["ids"]]).max() <= STATE_TOL * np.abs(full).max(), f"field {i} differs on rank {r}"
+    assert (seen == 1).all() and 0 < curved.size < mesh.numElements
+    assert np.abs(ref[1] - q0[1]).max() > 1e-5                   # the state did move
+
+
 def test_bad_tables_are_refused_before_anything_runs():
     d = np.load(CURVED[0])
     ctx, cub, gauss = contexts_from_fixture(d)
