@@ -149,7 +149,10 @@ hipError_t launchNT(const CurvedParams& p, hipStream_t stream, size_t lds) {
     // resident workgroups: WAVES per SIMD = WAVES workgroups of four waves per CU, as far as LDS allows
     const int wgPerCu = std::max(1, std::min<int>(WAVES, static_cast<int>(kLdsLimitBytes / std::max<size_t>(lds, 1))));
     const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u, wgs = (ntiles + 3u) / 4u;
-    const unsigned grid = std::max(1u, std::min(wgs, 256u * static_cast<unsigned>(wgPerCu) * (STREAM ? 1u : 2u)));
+    static const unsigned rounds = [] { const char* e = std::getenv("BDG_SW2D_CURVED_ROUNDS"); return e ? static_cast<unsigned>(std::atoi(e)) : 0u; }();
+    // one resident round of workgroups (each wave loops over its tiles): a second round re-stages the operator image and balances
+    // no better (BDG_SW2D_CURVED_ROUNDS=2..4 measured 1-4 % slower at N = 3, 6, 8)
+    const unsigned grid = std::max(1u, std::min(wgs, 256u * static_cast<unsigned>(wgPerCu) * (rounds ? rounds : 1u)));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
