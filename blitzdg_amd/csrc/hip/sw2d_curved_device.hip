@@ -89,7 +89,7 @@ struct bdg_sw2d_curved {
     // nodal-trace form (sw2d_curved_nt_kernel.hpp): used when the context has the structure it needs (useNT)
     bool useNT = false;
     Buf<double> opsNT, elAffine, gaussWref;
-    Buf<int> nodeP, faceFlags;
+    Buf<int> nodeP, faceFlags, faceNodesDev;
     int numAffineNT = 0;
     double g = 9.81, fconst = 0.0, cdconst = 0.0;
     long long stageCount = 0;
@@ -126,7 +126,7 @@ struct bdg_sw2d_curved {
         p.affineEl = numAffine ? affineEl.p : nullptr; p.cubAffine = numAffine ? cubAffine.p : nullptr; p.cubWref = cubWref.p;
         p.ops = ops.p; p.filt = filt.p; p.ld = ld; p.K = K; p.ncb = ncb; p.ncub = ncub; p.ng = ng; p.fb = fb; p.g = g;
         if (useNT) {
-            p.opsNT = opsNT.p; p.nodeP = nodeP.p; p.faceFlags = faceFlags.p; p.gaussWref = gaussWref.p;
+            p.opsNT = opsNT.p; p.nodeP = nodeP.p; p.faceFlags = faceFlags.p; p.faceNodes = faceNodesDev.p; p.gaussWref = gaussWref.p;
             p.affineEl = nullptr; p.elAffine = elAffine.p; // (the straight-element flag rides in faceFlags)
             static const int interleave = [] { const char* e = std::getenv("BDG_SW2D_TILE_INTERLEAVE"); return e ? std::atoi(e) : 1; }();
             p.tileInterleave = interleave;
@@ -346,6 +346,11 @@ void buildNodalTraceTables(bdg_sw2d_curved& s, const bdg_sw2d_curved_desc& d, co
     hipOk(hipMemcpyAsync(s.faceFlags.p, flags.data(), flags.size() * sizeof(int), hipMemcpyHostToDevice, st), "face flags upload");
     s.nodeP.alloc(static_cast<size_t>(rowsP) * ld, s.bytes, st);
     s.uploadRows(nodeP.data(), s.nodeP.p, rowsP);
+    std::vector<int> fnodes(static_cast<size_t>(rowsP));
+    for (int f = 0; f < 3; ++f)
+        for (int i = 0; i < KE * 4; ++i) fnodes[static_cast<size_t>(f) * KE * 4 + i] = faceNodes[f][i < Nfp ? i : 0];
+    s.faceNodesDev.alloc(fnodes.size(), s.bytes, st);
+    hipOk(hipMemcpyAsync(s.faceNodesDev.p, fnodes.data(), fnodes.size() * sizeof(int), hipMemcpyHostToDevice, st), "face nodes upload");
 
     // ---- operator image (CurvedOpsNT)
     std::vector<double> img(static_cast<size_t>(kt->ntTiles(ncb, fb)) * 64, 0.0);
@@ -375,18 +380,14 @@ void buildNodalTraceTables(bdg_sw2d_curved& s, const bdg_sw2d_curved_desc& d, co
         }
         for (int gb = 0; gb < 3 * fb; ++gb) {
             const int base = offSurf + gb * SCH, f = gb / fb, b = gb % fb;
-            for (int t = 0; t < KV; ++t) {
-                const int local = 16 * b + i, m = 4 * t + sc;
-                if (local < NG && m < Np) at(base + t, l) = I[static_cast<size_t>(f * NG + local) * Np + m];
-            }
             for (int t2 = 0; t2 < KE; ++t2) {
                 const int local = 16 * b + i, fn = 4 * t2 + sc;
-                if (local < NG && fn < Nfp) at(base + KV + t2, l) = IF(f, local, fn);
+                if (local < NG && fn < Nfp) at(base + t2, l) = IF(f, local, fn);
             }
             for (int r = 0; r < MT; ++r)
                 for (int reg = 0; reg < 4; ++reg) {
                     const int node = 16 * r + i, local = 16 * b + 4 * reg + sc;
-                    if (node < Np && local < NG) at(base + KV + KE + r * 4 + reg, l) = -I[static_cast<size_t>(f * NG + local) * Np + node];
+                    if (node < Np && local < NG) at(base + KE + r * 4 + reg, l) = -I[static_cast<size_t>(f * NG + local) * Np + node];
                 }
         }
         for (int r = 0; r < MT; ++r)

@@ -35,8 +35,8 @@ namespace bdg_dev {
 //                                  DrT[r][reg]      row 16 r + i = node, column s <-> cubature point 16 rb + 4 reg + s
 //                                  DsT[r][reg]
 //   surface block gb = f FB + b (SCH tiles):
-//                                  GI[t]            row = Gauss row 16 b + i of face f, column 4 t + s = node (Interp)
-//                                  GE[t2]           same rows, column 4 t2 + s = FACE node i of face f (Interp(:, Fmask(i, f)))
+//                                  GE[t2]           row = Gauss row 16 b + i of face f, column 4 t2 + s = FACE node of face f
+//                                                   (Interp(:, Fmask(:, f)): serves the exterior AND the own traces)
 //                                  IT[r][reg]       row 16 r + i = node, column s <-> Gauss row 16 b + 4 reg + s (-Interp^T)
 //   mass (3 MT KV tiles):          M[r][t] = V V^T,  MF[r][t] = Filter V V^T,  F[r][t] = Filter
 template <int N>
@@ -47,7 +47,7 @@ struct CurvedOpsNT {
     static constexpr int MT = (Np + 15) / 16;
     static constexpr int KE = (Nfp + 3) / 4;
     static constexpr int VCH = KV + 8 * MT;
-    static constexpr int SCH = KV + KE + 4 * MT;
+    static constexpr int SCH = KE + 4 * MT;
     __host__ __device__ static constexpr int offVol(int rb) { return rb * VCH; }
     __host__ __device__ static constexpr int offSurf(int ncb, int gb) { return ncb * VCH + gb * SCH; }
     __host__ __device__ static constexpr int offMass(int ncb, int fb) { return ncb * VCH + 3 * fb * SCH; }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
     constexpr int fb = FB;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-    // ---- LDS map (in tiles of 64 doubles): [stream buffers 2 VCH] [resident tiles] [wref 16 ncb] [gwref 16 FB]
+    // ---- LDS map (in tiles of 64 doubles): [stream buffers 2 VCH] [resident tiles] [wref 16 ncb] [gwref 16 FB] [face nodes, 12 KE ints]
     const int imgSurf = O::offSurf(ncb, 0), imgMass = O::offMass(ncb, fb);
     const int nSurf = 3 * fb * SCH;
     constexpr int massTiles = MT * KV;
@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
     const int ldsMass = STREAM ? ldsSurf + nSurf : imgMass + (FILTER ? massTiles : 0);
     const int ldsF = STREAM ? ldsMass + massTiles : imgMass + 2 * massTiles;
     const int ldsTiles = STREAM ? ldsMass + (FILTER ? 2 : 1) * massTiles : O::tiles(ncb, fb);
-    const int wrefAt = ldsTiles * 64, gwrefAt = wrefAt + 16 * ncb;
+    const int wrefAt = ldsTiles * 64, gwrefAt = wrefAt + 16 * ncb, fnAt = gwrefAt + 16 * fb;
+    int* const sFn = reinterpret_cast<int*>(sOps + fnAt);
 
     auto copyTiles = [&](const double* src, int dstTile, int ntile) { // all of a thread's 16-byte pieces of a batch in flight
         const f64x2* __restrict__ s2 = reinterpret_cast<const f64x2*>(src);
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
     }
     for (int t = threadIdx.x; t < 16 * ncb; t += blockDim.x) sOps[wrefAt + t] = p.cubWref ? p.cubWref[t] : 0.0;
     for (int t = threadIdx.x; t < 16 * fb; t += blockDim.x) sOps[gwrefAt + t] = p.gaussWref ? p.gaussWref[t] : 0.0;
+    for (int t = threadIdx.x; t < 12 * KE; t += blockDim.x) sFn[t] = p.faceNodes[t];
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
@@ -184,13 +186,19 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
         __builtin_amdgcn_sched_barrier(0);
         const bool affTile = __all((flags & 8) != 0); // straight-sided tile? (padding lanes repeat the last element)
 
-        // the neighbour's values at my face nodes (operand layout of GE) and, for a straight element, the face's nx, ny, W factor
-        auto gather = [&](int f, double (&qP)[4][KE], double (&fa)[3]) {
+        // the neighbour's values at my face nodes and my own (both in the operand layout of GE: the element's own rows were
+        // requested a moment ago by this wave, the second request finds them in cache) and, for a straight element, the face's
+        // nx, ny, W factor
+        auto gather = [&](int f, double (&qP)[4][KE], double (&qM)[4][KE], double (&fa)[3]) {
 #pragma unroll
             for (int t2 = 0; t2 < KE; ++t2) {
                 const unsigned oP = static_cast<unsigned>(idxP[f][t2]) * 8u;
+                const unsigned oM = (static_cast<unsigned>(sFn[f * KE * 4 + 4 * t2 + static_cast<int>(q)]) * static_cast<unsigned>(ld) + k) * 8u;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) qP[c][t2] = cbld_f64(rq, oP, static_cast<unsigned>(c) * planeB);
+                for (int c = 0; c < 4; ++c) {
+                    qP[c][t2] = cbld_f64(rq, oP, static_cast<unsigned>(c) * planeB);
+                    qM[c][t2] = cbld_f64(rq, oM, static_cast<unsigned>(c) * planeB);
+                }
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) fa[i] = cbld_f64(raff, k8, static_cast<unsigned>(4 + 3 * f + i) * ld8);
@@ -201,8 +209,11 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
         // cubature row / Gauss row / node: the bodies of the loops below are single basic blocks the scheduler can work in.
         auto body = [&](auto affC) {
             constexpr bool AFF = decltype(affC)::value;
-            double qP[4][KE], fa[3];
-            gather(0, qP, fa); // face 0's exterior nodes: the volume term hides their round trip
+            double qP[4][KE], qM[4][KE], fa[3];
+            // face 0's nodes on both sides: the volume term hides their round trip -- up to order 6. Beyond, a tile is > 100 us of
+            // products and the 28 registers are worth more than one exposed L2 round trip: requested after the volume term.
+            constexpr bool kGatherEarly = KV <= 8;
+            if constexpr (kGatherEarly) gather(0, qP, qM, fa);
             __builtin_amdgcn_sched_barrier(0);
 
             cmfma_t acc[4][MT];
@@ -297,6 +308,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                 }
             }
             if (!act) return; // (lockstep form: nothing but barriers above for a wave without a tile)
+            if constexpr (!kGatherEarly) gather(0, qP, qM, fa);
 
             // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face
 #pragma unroll
@@ -306,44 +318,32 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                 // One block per face: the exterior traces first, then the next face's nodes are requested while this face is
                 // worked on. Two blocks: each block forms its own exterior traces (16 fewer live doubles) and the request follows
                 // the last block's pointwise work, behind the face's lift products.
-                cmfma_t gP[4];
-                auto exteriorTraces = [&](int b) {
+                // Both traces at a block's 16 Gauss rows come from the face's N + 1 nodes (the interpolation rows of a face are zero
+                // off the face): KE k-steps per side with ONE A tile, instead of KV k-steps over the whole element for the own side.
+                cmfma_t gP[4], gM[4];
+                auto faceTraces = [&](int b) {
                     const int sbase = ldsSurf + (f * FB + b) * SCH;
+                    double a[KE];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) gP[c] = cmfma_zero();
+                    for (int t2 = 0; t2 < KE; ++t2) a[t2] = L(sbase + t2);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { gP[c] = cmfma_zero(); gM[c] = cmfma_zero(); }
 #pragma unroll
                     for (int t2 = 0; t2 < KE; ++t2) {
-                        const double a = L(sbase + KV + t2);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) gP[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, qP[c][t2], gP[c], 0, 0, 0);
+                        for (int c = 0; c < 4; ++c) {
+                            gP[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t2], qP[c][t2], gP[c], 0, 0, 0);
+                            gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t2], qM[c][t2], gM[c], 0, 0, 0);
+                        }
                     }
                 };
-                if constexpr (FB == 1) {
-                    exteriorTraces(0);
-                    if (f < 2) gather(f + 1, qP, fa);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if constexpr (FB == 1) faceTraces(0);
                 double lam = 0.0;
                 double ef[FB][4][4], dj[FB][4][4];
 #pragma unroll
                 for (int b = 0; b < FB; ++b) {
                     const int gb = f * FB + b;
-                    if constexpr (FB > 1) exteriorTraces(b);
-                    cmfma_t gM[4]; // the element's own traces at this block's 16 Gauss rows
-                    {
-                        const int sbase = ldsSurf + gb * SCH;
-                        double aG[KV];
-#pragma unroll
-                        for (int t = 0; t < KV; ++t) aG[t] = L(sbase + t);
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) gM[c] = cmfma_zero();
-#pragma unroll
-                        for (int t = 0; t < KV; ++t) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) gM[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aG[t], qB[c][t], gM[c], 0, 0, 0);
-                        }
-                    }
+                    if constexpr (FB > 1) faceTraces(b);
 #pragma unroll
                     for (int reg = 0; reg < (b == FB - 1 ? RL : 4); ++reg) {
                         const int local = 16 * b + static_cast<int>(q) + 4 * reg;
@@ -387,10 +387,8 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                 }
                 lam = fmax(lam, __shfl_xor(lam, 16)); // the face's Gauss points sit in the 4 lanes q of this element
                 lam = fmax(lam, __shfl_xor(lam, 32));
-                if constexpr (FB > 1) {
-                    if (f < 2) gather(f + 1, qP, fa);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if (f < 2) gather(f + 1, qP, qM, fa); // the next face's nodes: their round trip hides behind this face's lift products
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int b = 0; b < FB; ++b)
 #pragma unroll
@@ -398,7 +396,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                         double sf[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) sf[c] = fma(lam, dj[b][reg][c], ef[b][reg][c]);
-                        const int sbase = ldsSurf + (f * FB + b) * SCH + KV + KE;
+                        const int sbase = ldsSurf + (f * FB + b) * SCH + KE;
 #pragma unroll
                         for (int r = 0; r < MT; ++r) {
                             const double a = L(sbase + r * 4 + reg);
@@ -431,21 +429,22 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
             };
             // At high order the update reads the element's own state again (an L2 hit, requested with the residual rows) instead
             // of holding all 4 KV operand registers to the end of the tile: the compiler kept them in scratch, and every reload
-            // of a spilled register waits for ALL requests in flight.
-            constexpr bool REQ = KV > 8 && MODE != CMODE_RHS;
-            auto requestOld = [&](int c, double (&o)[KV], double (&own)[REQ ? KV : 1]) {
+            // of a spilled register waits for ALL requests in flight. (The sources still read h, hu, hv from the operand
+            // registers: reloading those too measured 6 % slower at N = 8.)
+            constexpr bool REQO = KV > 8 && MODE != CMODE_RHS;
+            auto requestOld = [&](int c, double (&o)[KV], double (&own)[REQO ? KV : 1]) {
                 if constexpr (MODE != CMODE_RHS) {
 #pragma unroll
                     for (int t = 0; t < KV; ++t) {
                         const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
                         o[t] = cbld_f64(rold, v8, so);
-                        if constexpr (REQ) own[t] = cbld_f64(rq, v8, so);
+                        if constexpr (REQO) own[t] = cbld_f64(rq, v8, so);
                     }
                 }
             };
             Rows rows[2];
             requestRows(0, rows[0]);
-            double oldv[2][KV], ownv[2][REQ ? KV : 1];
+            double oldv[2][KV], ownv[2][REQO ? KV : 1];
             requestOld(0, oldv[0], ownv[0]);
             __builtin_amdgcn_sched_barrier(0);
             double S2[KV], S3[KV], rjn[AFF ? 1 : KV];
@@ -512,7 +511,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                     if constexpr (!FILTER) R += c == 1 ? S2[t] : (c == 2 ? S3[t] : 0.0);
                     const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
                     double own = 0.0;
-                    if constexpr (REQ) own = ownv[c & 1][t];
+                    if constexpr (REQO) own = ownv[c & 1][t];
                     else if constexpr (MODE != CMODE_RHS) own = qB[c][t];
                     if constexpr (MODE == CMODE_RHS) {
                         cbst_f64(rout, vo, so, R);

@@ -118,9 +118,9 @@ int ntTiles(int ncb, int fb) { return ONT::tiles(ncb, fb); }
 void ntOffsets(int ncb, int fb, int* off) {
     off[0] = ONT::VCH; off[1] = ONT::SCH; off[2] = ONT::KE; off[3] = ONT::offSurf(ncb, 0); off[4] = ONT::offMass(ncb, fb);
 }
-size_t ntLdsResident(int ncb, int fb) { return (static_cast<size_t>(ONT::tiles(ncb, fb)) * 64 + 16 * ncb + 16 * fb) * sizeof(double); }
+size_t ntLdsResident(int ncb, int fb) { return (static_cast<size_t>(ONT::tiles(ncb, fb)) * 64 + 16 * ncb + 16 * fb + 6 * ONT::KE) * sizeof(double); }
 size_t ntLdsStreamed(int ncb, int fb, bool filter) {
-    return (static_cast<size_t>(2 * ONT::VCH + 3 * fb * ONT::SCH + (filter ? 2 : 1) * ONT::MT * ONT::KV) * 64 + 16 * ncb + 16 * fb) * sizeof(double);
+    return (static_cast<size_t>(2 * ONT::VCH + 3 * fb * ONT::SCH + (filter ? 2 : 1) * ONT::MT * ONT::KV) * 64 + 16 * ncb + 16 * fb + 6 * ONT::KE) * sizeof(double);
 }
 // Which forms are compiled for this order (compile time: every form is 24 kernels): the resident-image form up to order 6
 // (with the builders' default rules it fits there), the streamed form from order 5 on (BDG_SW2D_CURVED_STREAM=1 selects it
