@@ -89,7 +89,7 @@ struct bdg_sw2d_curved {
     // nodal-trace form (sw2d_curved_nt_kernel.hpp): used when the context has the structure it needs (useNT)
     bool useNT = false;
     Buf<double> opsNT, elAffine, gaussWref;
-    Buf<int> nodeP, faceFlags, faceNodesDev;
+    Buf<int> nodeP, faceFlags, faceNodesDev, tileOrder;
     int numAffineNT = 0;
     double g = 9.81, fconst = 0.0, cdconst = 0.0;
     long long stageCount = 0;
@@ -130,6 +130,9 @@ struct bdg_sw2d_curved {
             p.affineEl = nullptr; p.elAffine = elAffine.p; // (the straight-element flag rides in faceFlags)
             static const int interleave = [] { const char* e = std::getenv("BDG_SW2D_TILE_INTERLEAVE"); return e ? std::atoi(e) : 1; }();
             p.tileInterleave = interleave;
+            p.tileOrder = tileOrder.p;
+            static const int prioMode = [] { const char* e = std::getenv("BDG_SW2D_CURVED_PRIO"); return e ? std::atoi(e) : 2; }();
+            p.prioMode = prioMode;
         }
         return p;
     }
@@ -351,6 +354,35 @@ void buildNodalTraceTables(bdg_sw2d_curved& s, const bdg_sw2d_curved_desc& d, co
         for (int i = 0; i < KE * 4; ++i) fnodes[static_cast<size_t>(f) * KE * 4 + i] = faceNodes[f][i < Nfp ? i : 0];
     s.faceNodesDev.alloc(fnodes.size(), s.bytes, st);
     hipOk(hipMemcpyAsync(s.faceNodesDev.p, fnodes.data(), fnodes.size() * sizeof(int), hipMemcpyHostToDevice, st), "face nodes upload");
+
+    // ---- order of the tiles: positions [n x / 8, n (x + 1) / 8) of the list are XCD x's (sw2d_curved_nt_kernel); each eighth gets
+    //      an eighth of the general tiles (in mesh order, first), then straight-sided ones (in mesh order)
+    if (!std::getenv("BDG_SW2D_CURVED_NO_TILE_ORDER")) {
+        const int ntiles = (K + 15) / 16;
+        std::vector<int> general, straight, order;
+        for (int t = 0; t < ntiles; ++t) {
+            bool allStraight = true;
+            for (int k = 16 * t; k < std::min(K, 16 * t + 16); ++k) allStraight = allStraight && aff[k];
+            (allStraight ? straight : general).push_back(t);
+        }
+        const long long G = static_cast<long long>(general.size()), S = static_cast<long long>(straight.size());
+        if (G > 0 && S > 0 && ntiles >= 64) {
+            long long gi = 0, si = 0;
+            for (long long x = 0; x < 8; ++x) {
+                const long long cx = ntiles * (x + 1) / 8 - ntiles * x / 8;
+                long long gq = std::min({G * (x + 1) / 8 - G * x / 8, cx, G - gi}), sq = cx - gq;
+                if (sq > S - si) { sq = S - si; gq = cx - sq; }
+                for (long long i = 0; i < gq; ++i) order.push_back(general[static_cast<size_t>(gi + i)]);
+                for (long long i = 0; i < sq; ++i) order.push_back(straight[static_cast<size_t>(si + i)]);
+                gi += gq; si += sq;
+            }
+            if (gi == G && si == S && static_cast<int>(order.size()) == ntiles) {
+                s.tileOrder.alloc(order.size(), s.bytes, st);
+                hipOk(hipMemcpyAsync(s.tileOrder.p, order.data(), order.size() * sizeof(int), hipMemcpyHostToDevice, st), "tile order upload");
+                hipOk(hipStreamSynchronize(st), "tile order sync"); // (order is a local)
+            }
+        }
+    }
 
     // ---- operator image (CurvedOpsNT)
     std::vector<double> img(static_cast<size_t>(kt->ntTiles(ncb, fb)) * 64, 0.0);

@@ -74,9 +74,13 @@ struct CurvedParams {
     const int* nodeP;        // (3 * KE * 4, ld): offset row * ld + k of the neighbour's node at my face node (face f, node i) at row f * KE * 4 + i
     const int* faceFlags;    // ld: bit f set = face f is a wall; bit 3: straight element (elAffine holds its numbers)
     const int* faceNodes;    // 3 x 4 KE: node of face node i of face f (Fmask as Interp shows it; padding entries repeat the face's first node)
+    int prioMode;            // nodal-trace kernel, two workgroups per CU: see the tile loop (0: every wave at priority 0)
+    unsigned long long* phaseClock; // profiling builds (-DBDG_PHASE_CLOCK): 12 counts per wave of the nodal-trace kernel, else unused
     const double* elAffine;  // (14, ld), zeros on other elements: straight elements: W rx, W ry, W sx, W sy factors; nx, ny, W factor per face; 1 / J
     const double* gaussWref; // 16 fb: HALF the Gauss weights of a reference straight face (zero padded)
     int tileInterleave;      // 1: the waves of an XCD take its tiles side by side (default); 0: a contiguous run per wave
+    const int* tileOrder;    // (ntiles) or nullptr: list position -> tile, every XCD's eighth of the list holding an eighth of the
+                             // general (not all straight-sided) tiles: they cost more, and meshes keep them together
     const double* filt;   // (Np, Np) row-major filter for the fix-up kernel, or nullptr
     long long ld;
     int K;

@@ -63,6 +63,9 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
     using O = CurvedOpsNT<N>;
     constexpr int Np = O::Np, KV = O::KV, MT = O::MT, KE = O::KE, VCH = O::VCH, SCH = O::SCH;
     extern __shared__ double sOps[];
+#ifdef BDG_PHASE_CLOCK
+    const unsigned long long entryClk = __builtin_readcyclecounter(), entryReal = __builtin_amdgcn_s_memrealtime();
+#endif
     const int ncb = p.ncb;
     constexpr int fb = FB;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -131,27 +134,60 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
     // the mesh and the neighbours' face nodes a tile gathers are rows a sibling wave is streaming (p.tileInterleave = 0: one
     // contiguous run of tiles per wave, as in the first form). Every wave of an XCD makes the same number of passes (the
     // lockstep form needs that of a workgroup's waves: a wave without a tile keeps the barriers and the chunk copies company).
-    unsigned tile, tileEnd, tileStep, passes;
+    // p.tileOrder: the XCD's eighth of the LIST of tiles, which deals the tiles that are not all straight-sided (1.2-1.5 x the
+    // work, and next to each other in the mesh: the elements along a curved wall) evenly to the eight XCDs.
+    // (Not kept: positions handed out by a counter per XCD, so that the wave that loses the issue arbitration of its SIMD -- the
+    // younger of the two: at N = 4 the first workgroup of a CU ran its 8 tiles in 433 k cycles, the second its 7 in 556 k --
+    // takes fewer tiles. 256 waves drawing from one address: 0.14 -> 0.21 ms at N = 2, 0.195 -> 0.24 at N = 3, even at N >= 4.)
+    unsigned pos, tileEnd, tileStep, passes;
+    const int* order = nullptr;
     if (p.tileInterleave) {
+        if (gridDim.x >= 8u) order = p.tileOrder;
         const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, wgHere = nwg / 8u + (xcd < nwg % 8u ? 1u : 0u);
         const unsigned nx = nwg < 8u ? nwg : 8u; // XCDs that have a workgroup of this launch
         const unsigned t0 = static_cast<unsigned>((static_cast<unsigned long long>(ntiles) * xcd) / nx),
                        t1 = static_cast<unsigned>((static_cast<unsigned long long>(ntiles) * (xcd + 1u)) / nx);
         const unsigned wavesHere = wgHere * (blockDim.x >> 6), w = (blockIdx.x / 8u) * (blockDim.x >> 6) + (threadIdx.x >> 6);
-        tile = t0 + w;
+        pos = t0 + w;
         tileEnd = t1;
         tileStep = wavesHere;
         passes = (t1 - t0 + wavesHere - 1u) / wavesHere;
     } else {
-        curved_wave_tiles(ntiles, tile, tileEnd);
+        curved_wave_tiles(ntiles, pos, tileEnd);
         const unsigned nwavesAll = gridDim.x * (blockDim.x >> 6);
         tileStep = 1u;
-        passes = STREAM ? (ntiles + nwavesAll - 1u) / nwavesAll : (tileEnd > tile ? tileEnd - tile : 0u);
+        passes = STREAM ? (ntiles + nwavesAll - 1u) / nwavesAll : (tileEnd > pos ? tileEnd - pos : 0u);
     }
     int phase = 0; // stream buffer that holds the chunk about to be used
+#ifdef BDG_PHASE_CLOCK
+    // profiling build only: cycles a wave spends in each phase of a tile, summed over its tiles (0: requests of the tile's
+    // first round trip; 1: volume term (waits for them); 2: surface term; 3: sources; 4: mass products, update, stores)
+    unsigned long long clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp = __builtin_readcyclecounter();
+    clk[5] = stamp - entryClk; // operator image to LDS, descriptors, tile range
+    clk[8] = entryReal;        // 8, 9: entry and exit of the wave on the chip-wide 100 MHz counter
+    const unsigned long long clk0 = stamp, real0 = __builtin_amdgcn_s_memrealtime(); // 6, 7: the loop in shader cycles / in 100 MHz ticks
+#define BDG_NT_STAMP(i)                                                       \
+    {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        const unsigned long long now = __builtin_readcyclecounter();          \
+        clk[i] += now - stamp;                                                \
+        stamp = now;                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    }
+#else
+#define BDG_NT_STAMP(i)
+#endif
 
-    for (unsigned pass = 0; pass < passes; ++pass, tile += tileStep) {
-        const bool act = tile < tileEnd;
+    // Two workgroups per CU: the waves of the second one (dispatched later: blockIdx >= the number of CUs) lose every issue
+    // arbitration of their SIMD to the older wave (MI355X_MICROARCH.md, two waves per SIMD). p.prioMode gives them priority 1
+    // over a part of each tile, so that the two halves of the launch run at about the same speed and leave together.
+    const int prio = (!STREAM && blockIdx.x >= 256u && gridDim.x > 256u) ? p.prioMode : 0;
+    if (prio == 3) __builtin_amdgcn_s_setprio(1);
+    for (unsigned pass = 0; pass < passes; ++pass, pos += tileStep) {
+        const bool act = pos < tileEnd;
+        if (prio == 1) __builtin_amdgcn_s_setprio(1);
+        if (prio == 2) __builtin_amdgcn_s_setprio(0);
+        const unsigned tile = (order && act) ? static_cast<unsigned>(__builtin_amdgcn_readfirstlane(order[pos])) : pos;
         const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
         const bool live = act && kTrue <= kLast;
         const unsigned k = (act && kTrue <= kLast) ? kTrue : kLast; // padding lanes recompute the last element, store nothing
@@ -185,6 +221,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
         ea[4] = cbld_f64(raff, k8, 13u * ld8);
         __builtin_amdgcn_sched_barrier(0);
         const bool affTile = __all((flags & 8) != 0); // straight-sided tile? (padding lanes repeat the last element)
+        BDG_NT_STAMP(0)
 
         // the neighbour's values at my face nodes and my own (both in the operand layout of GE: the element's own rows were
         // requested a moment ago by this wave, the second request finds them in cache) and, for a straight element, the face's
@@ -308,7 +345,50 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                 }
             }
             if (!act) return; // (lockstep form: nothing but barriers above for a wave without a tile)
+            BDG_NT_STAMP(1)
+            if (prio == 1) __builtin_amdgcn_s_setprio(0);
+            if (prio == 2) __builtin_amdgcn_s_setprio(1);
             if constexpr (!kGatherEarly) gather(0, qP, qM, fa);
+
+            // ---- what the last phase (mass inverse, sources, update) reads
+            // Rows of this phase -- the source tables, 1 / J on general tiles, the residual / base state of the update -- are
+            // requested TC k-steps (one field) ahead of their use: everything at once is 17 rows per k-step, 400 registers at N = 8.
+            // Order: sources at every node first (S2, S3), then ONE field at a time: mass products (and Filter S for the momentum
+            // fields), update, stores -- MT result tiles live instead of 4 MT.
+            constexpr int TC = KV < 4 ? KV : 4, NCH = (KV + TC - 1) / TC;
+            struct Rows { double cf[TC], cd[TC], zx[TC], zy[TC], rj[TC]; };
+            auto requestRows = [&](int ch, Rows& w) {
+#pragma unroll
+                for (int i = 0; i < TC; ++i) {
+                    const int t = ch * TC + i;
+                    if (t >= KV) break;
+                    const unsigned so = static_cast<unsigned>(4 * t) * ld8, vo = nodeOff(t);
+                    if constexpr (!AFF) w.rj[i] = cbld_f64(rcoef, vo, so); // 0 on padding rows
+                    w.cf[i] = p.fcor ? cbld_f64(rcoef, vo, soFc + so) : p.fconst;
+                    w.cd[i] = p.cd ? cbld_f64(rcoef, vo, soCd + so) : p.cdconst;
+                    w.zx[i] = p.zx ? cbld_f64(rcoef, vo, soZx + so) : 0.0;
+                    w.zy[i] = p.zy ? cbld_f64(rcoef, vo, soZy + so) : 0.0;
+                }
+            };
+            // At high order the update reads the element's own state again (an L2 hit, requested with the residual rows) instead
+            // of holding all 4 KV operand registers to the end of the tile: the compiler kept them in scratch, and every reload
+            // of a spilled register waits for ALL requests in flight. (The sources still read h, hu, hv from the operand
+            // registers: reloading those too measured 6 % slower at N = 8.)
+            constexpr bool REQO = KV > 8 && MODE != CMODE_RHS;
+            auto requestOld = [&](int c, double (&o)[KV], double (&own)[REQO ? KV : 1]) {
+                if constexpr (MODE != CMODE_RHS) {
+#pragma unroll
+                    for (int t = 0; t < KV; ++t) {
+                        const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
+                        o[t] = cbld_f64(rold, v8, so);
+                        if constexpr (REQO) own[t] = cbld_f64(rq, v8, so);
+                    }
+                }
+            };
+            Rows rows[2];
+            double oldv[2][KV], ownv[2][REQO ? KV : 1];
+            // (Not kept: the first of these requests behind the last face's lift products, in the registers of the face nodes --
+            // no gain at N = 2, 3, 5, 6, and 28 spilled registers at N = 4.)
 
             // ---- surface term, face by face; Gauss row of this lane: 16 b + q + 4 reg of the face
 #pragma unroll
@@ -406,45 +486,10 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                     }
             }
 
+            BDG_NT_STAMP(2)
             // ---- mass inverse, sources, update. acc[c][t >> 2][t & 3] is node m = 4 t + q: the operand layout again.
             const int slot = p.curvedSlot ? p.curvedSlot[k] : -1;
-            // Rows of this phase -- the source tables, 1 / J on general tiles, the residual / base state of the update -- are
-            // requested TC k-steps (one field) ahead of their use: everything at once is 17 rows per k-step, 400 registers at N = 8.
-            // Order: sources at every node first (S2, S3), then ONE field at a time: mass products (and Filter S for the momentum
-            // fields), update, stores -- MT result tiles live instead of 4 MT.
-            constexpr int TC = KV < 4 ? KV : 4, NCH = (KV + TC - 1) / TC;
-            struct Rows { double cf[TC], cd[TC], zx[TC], zy[TC], rj[TC]; };
-            auto requestRows = [&](int ch, Rows& w) {
-#pragma unroll
-                for (int i = 0; i < TC; ++i) {
-                    const int t = ch * TC + i;
-                    if (t >= KV) break;
-                    const unsigned so = static_cast<unsigned>(4 * t) * ld8, vo = nodeOff(t);
-                    if constexpr (!AFF) w.rj[i] = cbld_f64(rcoef, vo, so); // 0 on padding rows
-                    w.cf[i] = p.fcor ? cbld_f64(rcoef, vo, soFc + so) : p.fconst;
-                    w.cd[i] = p.cd ? cbld_f64(rcoef, vo, soCd + so) : p.cdconst;
-                    w.zx[i] = p.zx ? cbld_f64(rcoef, vo, soZx + so) : 0.0;
-                    w.zy[i] = p.zy ? cbld_f64(rcoef, vo, soZy + so) : 0.0;
-                }
-            };
-            // At high order the update reads the element's own state again (an L2 hit, requested with the residual rows) instead
-            // of holding all 4 KV operand registers to the end of the tile: the compiler kept them in scratch, and every reload
-            // of a spilled register waits for ALL requests in flight. (The sources still read h, hu, hv from the operand
-            // registers: reloading those too measured 6 % slower at N = 8.)
-            constexpr bool REQO = KV > 8 && MODE != CMODE_RHS;
-            auto requestOld = [&](int c, double (&o)[KV], double (&own)[REQO ? KV : 1]) {
-                if constexpr (MODE != CMODE_RHS) {
-#pragma unroll
-                    for (int t = 0; t < KV; ++t) {
-                        const unsigned so = static_cast<unsigned>(c) * planeB + static_cast<unsigned>(4 * t) * ld8;
-                        o[t] = cbld_f64(rold, v8, so);
-                        if constexpr (REQO) own[t] = cbld_f64(rq, v8, so);
-                    }
-                }
-            };
-            Rows rows[2];
             requestRows(0, rows[0]);
-            double oldv[2][KV], ownv[2][REQO ? KV : 1];
             requestOld(0, oldv[0], ownv[0]);
             __builtin_amdgcn_sched_barrier(0);
             double S2[KV], S3[KV], rjn[AFF ? 1 : KV];
@@ -468,6 +513,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
                     S3[t] = m < Np ? -(w.cf[i] * hu - cdn * v) - g * h * w.zy[i] : 0.0;
                 }
             }
+            BDG_NT_STAMP(3)
             if (live && slot >= 0) { // element of curvedEls: its own mass matrix is applied by the fix-up kernel
 #pragma unroll
                 for (int c = 0; c < 4; ++c)
@@ -527,7 +573,18 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
         };
         if (affTile) body(std::true_type{});
         else body(std::false_type{});
+        BDG_NT_STAMP(4)
     }
+#ifdef BDG_PHASE_CLOCK
+    clk[6] = __builtin_readcyclecounter() - clk0;
+    clk[7] = __builtin_amdgcn_s_memrealtime() - real0;
+    clk[9] = __builtin_amdgcn_s_memrealtime();
+    if (p.phaseClock != nullptr && lane == 0 && blockIdx.x < 1024u) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) p.phaseClock[(blockIdx.x * 4u + (threadIdx.x >> 6)) * 12u + i] = clk[i];
+    }
+#endif
+#undef BDG_NT_STAMP
 }
 
 } // namespace bdg_dev

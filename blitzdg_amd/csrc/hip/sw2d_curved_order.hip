@@ -2,7 +2,9 @@
 #include "sw2d_curved_kernel.hpp"
 #include "sw2d_curved_nt_kernel.hpp"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #ifndef BDG_ORDER
 #error "compile with -DBDG_ORDER=<polynomial order>"
@@ -153,8 +155,34 @@ hipError_t launchNT(const CurvedParams& p, hipStream_t stream, size_t lds) {
     // one resident round of workgroups (each wave loops over its tiles): a second round re-stages the operator image and balances
     // no better (BDG_SW2D_CURVED_ROUNDS=2..4 measured 1-4 % slower at N = 3, 6, 8)
     const unsigned grid = std::max(1u, std::min(wgs, 256u * static_cast<unsigned>(wgPerCu) * (rounds ? rounds : 1u)));
+#ifdef BDG_PHASE_CLOCK
+    // profiling build: the per-wave phase cycles of the last launch (workgroups 0..1023) go to $BDG_PHASE_CLOCK_FILE when the
+    // process exits (pinned host memory the kernel writes directly, so nothing of HIP is needed at that point)
+    static unsigned long long* clockBuf = nullptr;
+    if (!clockBuf) {
+        if (hipHostMalloc(&clockBuf, 4096 * 12 * sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return hipErrorOutOfMemory;
+        std::memset(clockBuf, 0, 4096 * 12 * sizeof(unsigned long long));
+        static unsigned long long* dump = clockBuf;
+        std::atexit([] {
+            const char* name = std::getenv("BDG_PHASE_CLOCK_FILE");
+            if (FILE* f = name ? std::fopen(name, "w") : nullptr) {
+                for (unsigned w = 0; w < 4096; ++w) {
+                    std::fprintf(f, "%u", w);
+                    for (int i = 0; i < 12; ++i) std::fprintf(f, " %llu", dump[w * 12 + i]);
+                    std::fprintf(f, "\n");
+                }
+                std::fclose(f);
+            }
+        });
+    }
+    CurvedParams pc = p;
+    pc.phaseClock = clockBuf;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, pc);
+    return hipGetLastError();
+#else
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
     return hipGetLastError();
+#endif
 }
 
 // Compiled shapes of the face blocks: the builders' default rule NGauss = 2 (N + 1) exactly -- FB blocks per face, RL live 4-row
