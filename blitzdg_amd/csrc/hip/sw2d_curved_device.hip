@@ -4,6 +4,7 @@
 #include "../host/capi_internal.hpp"
 #include "../host/parallel_for.hpp"
 #include "blitzdg/LSERK4.hpp"
+#include "rccl_api.hpp"
 #include "sw2d_curved_kernel.hpp"
 #include <algorithm>
 #include <atomic>
@@ -69,6 +70,23 @@ struct Buf {
     ~Buf() { release(); }
 };
 
+// Ghost exchange of a partitioned run: one record of 4 Np doubles ([field][node]) per element. Pack: the elements a
+// neighbour needs, in the order of the send list; unpack: the received records into the ghost columns (num_owned ...).
+__global__ __launch_bounds__(256) void sw2d_curved_pack_kernel(const double* __restrict__ q, long long ld, int rows,
+                                                               const int* __restrict__ sendEls, int numSend, double* __restrict__ out) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long long>(numSend) * rows) return;
+    const int rec = static_cast<int>(i / rows), row = static_cast<int>(i - static_cast<long long>(rec) * rows);
+    out[i] = q[static_cast<long long>(row) * ld + sendEls[rec]];
+}
+__global__ __launch_bounds__(256) void sw2d_curved_unpack_kernel(double* __restrict__ q, long long ld, int rows, int firstGhost,
+                                                                 int numGhost, const double* __restrict__ in) {
+    const long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= static_cast<long long>(numGhost) * rows) return;
+    const int row = static_cast<int>(i / numGhost), gcol = static_cast<int>(i - static_cast<long long>(row) * numGhost); // coalesced writes
+    q[static_cast<long long>(row) * ld + firstGhost + gcol] = in[static_cast<long long>(gcol) * rows + row];
+}
+
 } // namespace
 
 struct bdg_sw2d_curved {
@@ -94,8 +112,17 @@ struct bdg_sw2d_curved {
     double g = 9.81, fconst = 0.0, cdconst = 0.0;
     long long stageCount = 0;
     double bytesPerElement = 0.0;
+    // partitioned runs (bdg_sw2d_curved_set_partition / _comm_init): elements [numOwned, K) are ghosts, refreshed from their
+    // owners before every evaluation by grouped ncclSend / ncclRecv on the solver's stream
+    struct Peer { int rank, sendStart, sendCount, recvStart, recvCount; };
+    int numOwned = 0, numSend = 0, commRank = 0, commWorld = 1;
+    Buf<int> sendEls;
+    Buf<double> sendBuf, recvBuf;
+    std::vector<Peer> peers;
+    ncclComm_t comm = nullptr;
 
     ~bdg_sw2d_curved() {
+        if (comm) (void)bdg_rccl::rccl().CommDestroy(comm);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -165,6 +192,45 @@ struct bdg_sw2d_curved {
         }
     }
 
+    // ghost columns of `state` from their owners (pack -> grouped send / receive with every neighbour -> unpack), in stream order
+    void exchange(double* state) {
+        if (!comm) throw arg_error("bdg_sw2d_curved: no communicator (call bdg_sw2d_curved_comm_init first)");
+        const int rows = 4 * Np, ghosts = K - numOwned;
+        if (numSend > 0) {
+            const long long n = static_cast<long long>(numSend) * rows;
+            hipLaunchKernelGGL(sw2d_curved_pack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, state, ld,
+                               rows, sendEls.p, numSend, sendBuf.p);
+            hipOk(hipGetLastError(), "sw2d_curved_pack_kernel");
+        }
+        if (!peers.empty()) {
+            bdg_rccl::RcclApi& nc = bdg_rccl::rccl();
+            bdg_rccl::ncclCheck(nc.GroupStart(), "ncclGroupStart");
+            for (const Peer& pr : peers) {
+                if (pr.recvCount > 0)
+                    bdg_rccl::ncclCheck(nc.Recv(recvBuf.p + static_cast<size_t>(pr.recvStart) * rows, static_cast<size_t>(pr.recvCount) * rows,
+                                                ncclDouble, pr.rank, comm, stream), "ncclRecv");
+                if (pr.sendCount > 0)
+                    bdg_rccl::ncclCheck(nc.Send(sendBuf.p + static_cast<size_t>(pr.sendStart) * rows, static_cast<size_t>(pr.sendCount) * rows,
+                                                ncclDouble, pr.rank, comm, stream), "ncclSend");
+            }
+            bdg_rccl::ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
+        }
+        if (ghosts > 0) {
+            const long long n = static_cast<long long>(ghosts) * rows;
+            hipLaunchKernelGGL(sw2d_curved_unpack_kernel, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, stream, state, ld,
+                               rows, numOwned, ghosts, recvBuf.p);
+            hipOk(hipGetLastError(), "sw2d_curved_unpack_kernel");
+        }
+    }
+    // the driver's RK2 step of a partitioned run: an exchange in front of EACH evaluation, of the state that evaluation reads
+    void stepRk2Exchanged(double dt, int steps, bool filter) {
+        for (int i = 0; i < steps; ++i) {
+            exchange(qA.p);
+            evaluate(bdg_dev::CMODE_COMBINE, filter, qA.p, qA.p, qB.p, 1.0, 0.0, 0.5 * dt);
+            exchange(qB.p);
+            evaluate(bdg_dev::CMODE_COMBINE, filter, qB.p, qA.p, qA.p, 1.0, 0.0, dt);
+        }
+    }
     void stepRk2(double dt, int steps, bool filter) {
         for (int i = 0; i < steps; ++i) {
             evaluate(bdg_dev::CMODE_COMBINE, filter, qA.p, qA.p, qB.p, 1.0, 0.0, 0.5 * dt); // predictor: q1 = q + dt/2 RHS(q)
@@ -890,6 +956,88 @@ int bdg_sw2d_curved_rk2_phase(bdg_sw2d_curved* s, double dt, int phase, int filt
         s->use();
         if (phase == 0) s->evaluate(bdg_dev::CMODE_COMBINE, filter != 0, s->qA.p, s->qA.p, s->qB.p, 1.0, 0.0, 0.5 * dt);
         else s->evaluate(bdg_dev::CMODE_COMBINE, filter != 0, s->qB.p, s->qA.p, s->qA.p, 1.0, 0.0, dt);
+    });
+}
+
+int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_owned, const int* send_elements, int num_send) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_set_partition");
+        if (num_owned < 1 || num_owned > s->K || num_send < 0 || (num_send > 0 && !send_elements))
+            throw arg_error("bdg_sw2d_curved_set_partition: bad argument");
+        for (int i = 0; i < num_send; ++i)
+            if (send_elements[i] < 0 || send_elements[i] >= num_owned)
+                throw arg_error("bdg_sw2d_curved_set_partition: a send element is not an owned element");
+        if (s->comm) throw arg_error("bdg_sw2d_curved_set_partition: the communicator is already initialised");
+        s->use();
+        s->numOwned = num_owned;
+        s->numSend = num_send;
+        s->sendEls.alloc(static_cast<size_t>(std::max(1, num_send)), s->bytes, s->stream);
+        if (num_send > 0)
+            hipOk(hipMemcpyAsync(s->sendEls.p, send_elements, static_cast<size_t>(num_send) * sizeof(int), hipMemcpyHostToDevice, s->stream),
+                  "send list upload");
+        hipOk(hipStreamSynchronize(s->stream), "send list sync");
+    });
+}
+
+int bdg_sw2d_curved_comm_init(bdg_sw2d_curved* s, int rank, int world, const void* unique_id, const int* peer_ranks,
+                              const int* send_start, const int* send_count, const int* recv_start, const int* recv_count,
+                              int num_peers) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_comm_init");
+        if (!unique_id || world < 1 || rank < 0 || rank >= world || num_peers < 0 ||
+            (num_peers > 0 && (!peer_ranks || !send_start || !send_count || !recv_start || !recv_count)))
+            throw arg_error("bdg_sw2d_curved_comm_init: bad argument");
+        if (s->comm) throw arg_error("bdg_sw2d_curved_comm_init: communicator already initialised");
+        if (s->numOwned < 1) throw arg_error("bdg_sw2d_curved_comm_init: call bdg_sw2d_curved_set_partition first");
+        const int ghosts = s->K - s->numOwned;
+        std::vector<bdg_sw2d_curved::Peer> peers;
+        for (int i = 0; i < num_peers; ++i) {
+            const bdg_sw2d_curved::Peer p{peer_ranks[i], send_start[i], send_count[i], recv_start[i], recv_count[i]};
+            if (p.rank < 0 || p.rank >= world || p.sendStart < 0 || p.sendCount < 0 || p.sendStart + p.sendCount > s->numSend ||
+                p.recvStart < 0 || p.recvCount < 0 || p.recvStart + p.recvCount > ghosts)
+                throw arg_error("bdg_sw2d_curved_comm_init: peer ranges do not fit the partition set with bdg_sw2d_curved_set_partition");
+            peers.push_back(p);
+        }
+        s->use();
+        ncclUniqueId id;
+        std::memcpy(&id, unique_id, sizeof(id));
+        bdg_rccl::ncclCheck(bdg_rccl::rccl().CommInitRank(&s->comm, world, id, rank), "ncclCommInitRank");
+        s->commRank = rank;
+        s->commWorld = world;
+        s->peers = peers;
+        const size_t rows = static_cast<size_t>(4) * s->Np;
+        s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes, s->stream);
+        s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes, s->stream);
+        hipOk(hipStreamSynchronize(s->stream), "exchange buffers");
+    });
+}
+
+int bdg_sw2d_curved_step_rk2_exchanged(bdg_sw2d_curved* s, double dt, int num_steps, int filter) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_step_rk2_exchanged");
+        if (num_steps < 0) throw arg_error("bdg_sw2d_curved_step_rk2_exchanged: num_steps < 0");
+        s->use();
+        s->stepRk2Exchanged(dt, num_steps, filter != 0);
+    });
+}
+
+int bdg_sw2d_curved_exchange(bdg_sw2d_curved* s, int intermediate) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_exchange");
+        s->use();
+        s->exchange(intermediate ? s->qB.p : s->qA.p);
+    });
+}
+
+int bdg_sw2d_curved_barrier(bdg_sw2d_curved* s) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_barrier");
+        if (!s->comm) throw arg_error("bdg_sw2d_curved_barrier: no communicator");
+        s->use();
+        hipOk(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+        double* scratch = s->sendBuf.p; // (idle between exchanges; one double is all the reduction touches)
+        bdg_rccl::ncclCheck(bdg_rccl::rccl().AllReduce(scratch, scratch, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce");
+        hipOk(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
     });
 }
 

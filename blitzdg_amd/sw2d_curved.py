@@ -156,8 +156,8 @@ class DistributedSw2dCurved:
     ``torch.distributed`` (gloo: host tensors; nccl = RCCL: device tensors). Ghost elements are computed like any other (their
     outer faces are walls of the local mesh) and their results are discarded -- overwritten by the next exchange.
 
-    A functional path (host-staged columns, no overlap with the interior elements); the overlapped, RCCL-native schedule of the
-    straight-element solver (halo.NativeDistributedSw2d) has no curved counterpart yet."""
+    A functional path (host-staged columns); NativeDistributedSw2dCurved below drives the same exchange from the library over
+    RCCL, device to device."""
 
     def __init__(self, plan, order, deform, dist, g=9.81, filter_args=None, sources=None, device=0):
         """deform(x0, y0) -> (x, y): node coordinates of the curved mesh from the straight ones (elements it moves are listed in
@@ -182,7 +182,6 @@ class DistributedSw2dCurved:
                                        f=src.get("f", 0.0), CD=src.get("CD", 0.0), device=device)
         self.nodes, self.ctx, self.cub, self.x, self.y = nodes, ctx, cub, x, y
         self.filtered = filter_args is not None
-        self._torch = __import__("torch")
         self._on_device = dist.get_backend() == "nccl"
 
     def set_initial_state(self, fn):
@@ -190,7 +189,8 @@ class DistributedSw2dCurved:
 
     def _exchange(self, intermediate):
         """Ghost columns of the state the next evaluation reads, from their owners."""
-        plan, torch, dist = self.plan, self._torch, self.dist
+        import torch
+        plan, dist = self.plan, self.dist
         n_own, n_int = plan.num_owned, plan.num_interior
         rows = 4 * self.solver.Np
         boundary = self.solver.getElements(n_int, n_own - n_int, intermediate)          # the partition-boundary block
@@ -217,3 +217,68 @@ class DistributedSw2dCurved:
     def owned_state(self):
         n = self.plan.num_owned
         return (self.plan.own_global,) + tuple(a[:, :n] for a in self.solver.getState())
+
+
+class NativeDistributedSw2dCurved(DistributedSw2dCurved):
+    """DistributedSw2dCurved with the ghost exchange driven by the C++ library: pack kernel, grouped ncclSend / ncclRecv with
+    every neighbour on the solver's stream, unpack kernel -- device to device over RCCL (xGMI), whole step loops in one C call,
+    no PyTorch. One process per rank; rank 0's RCCL id reaches the others through halo.file_rendezvous (or pass unique_id).
+    Not overlapped with the evaluation: every element of the nodal-trace kernel may gather from a ghost column."""
+
+    def __init__(self, plan, order, deform, g=9.81, filter_args=None, sources=None, device=0, unique_id=None, loopback=False):
+        """loopback=True: this one process computes plan.rank's share of a plan.world-way split and every neighbour exchange
+        is a send-to-self of the same size through the real transport (ghost values are then this rank's own boundary
+        elements, not the neighbours': a rehearsal of the exchange on one GPU, not a partitioned result)."""
+        import ctypes
+        import os
+
+        from ._capi import ptr
+        from .halo import file_rendezvous
+
+        class _NoDist:                    # the base class only asks its transport for the backend name
+            @staticmethod
+            def get_backend():
+                return "native"
+        super().__init__(plan, order, deform, _NoDist(), g=g, filter_args=filter_args, sources=sources, device=device)
+        h = self.solver._h
+        send = np.ascontiguousarray(plan.send_local, dtype=np.int32)
+        check(lib.bdg_sw2d_curved_set_partition(h, plan.num_owned, ptr(send), send.size))
+        id_path = None
+        comm_rank, comm_world = plan.rank, plan.world
+
+        def make_id():
+            buf = ctypes.create_string_buffer(128)
+            check(lib.bdg_comm_unique_id(buf, 128))
+            return buf.raw
+        if loopback:
+            comm_rank, comm_world, unique_id = 0, 1, make_id()
+        if unique_id is None:
+            unique_id, id_path = file_rendezvous(plan.rank, plan.world, make_id)
+        recv_of = {peer: (start, count) for peer, start, count in plan.recv_slices}
+        send_of = {peer: (start, count) for peer, start, count in plan.send_slices}
+        peers = sorted(set(recv_of) | set(send_of))
+        arr = lambda vals: np.ascontiguousarray(vals, dtype=np.int32)  # noqa: E731
+        pr = arr(peers)
+        ss, sc = arr([send_of.get(p, (0, 0))[0] for p in peers]), arr([send_of.get(p, (0, 0))[1] for p in peers])
+        rs, rc = arr([recv_of.get(p, (0, 0))[0] for p in peers]), arr([recv_of.get(p, (0, 0))[1] for p in peers])
+        if loopback:
+            pr = arr([0] * len(peers))
+            sc = rc = np.minimum(sc, rc)
+        self.peer_table = (pr, ss, sc, rs, rc)
+        idbuf = ctypes.create_string_buffer(unique_id, 128)
+        check(lib.bdg_sw2d_curved_comm_init(h, comm_rank, comm_world, idbuf, ptr(pr), ptr(ss), ptr(sc), ptr(rs), ptr(rc), len(peers)))
+        self.barrier()
+        if id_path is not None and plan.rank == 0:
+            try:
+                os.remove(id_path)
+            except OSError:
+                pass
+
+    def _exchange(self, intermediate):
+        check(lib.bdg_sw2d_curved_exchange(self.solver._h, int(bool(intermediate))))
+
+    def step_rk2(self, dt, nsteps=1):
+        check(lib.bdg_sw2d_curved_step_rk2_exchanged(self.solver._h, float(dt), int(nsteps), int(self.filtered)))
+
+    def barrier(self):
+        check(lib.bdg_sw2d_curved_barrier(self.solver._h))

@@ -466,6 +466,20 @@ int bdg_sw2d_curved_set_elements(bdg_sw2d_curved* s, int which, int first, int c
 /* One half of the driver's step (sw2d_curved.py:246-277), so that a ghost exchange fits between the two evaluations:
  * phase 0 -- predictor, intermediate = state + dt/2 RHS(state); phase 1 -- corrector, state += dt RHS(intermediate). */
 int bdg_sw2d_curved_rk2_phase(bdg_sw2d_curved* s, double dt, int phase, int filter);
+/* The same exchange driven by this library over RCCL (point-to-point over xGMI; bound with dlopen on first use, as for
+ * bdg_sw2d_comm_init, whose id -- bdg_comm_unique_id -- and neighbour tables it takes): elements [num_owned, K) of the solver's
+ * mesh are ghosts; peer i is sent the elements send_elements[send_start[i] .. + send_count[i]) and its recv_count[i] elements
+ * arrive in ghost slots recv_start[i] .. (relative to num_owned); one record of 4 Np doubles per element. step_rk2_exchanged =
+ * num_steps times {exchange(state), predictor, exchange(intermediate), corrector}, all in stream order on the device (not
+ * overlapped with the evaluation: every element of the nodal-trace kernel may gather from a ghost). exchange: one refresh by
+ * itself (which as above). barrier: drains the stream, meets every rank (an 8-byte all-reduce), drains again. */
+int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_owned, const int* send_elements, int num_send);
+int bdg_sw2d_curved_comm_init(bdg_sw2d_curved* s, int rank, int world, const void* unique_id, const int* peer_ranks,
+                              const int* send_start, const int* send_count, const int* recv_start, const int* recv_count,
+                              int num_peers);
+int bdg_sw2d_curved_step_rk2_exchanged(bdg_sw2d_curved* s, double dt, int num_steps, int filter);
+int bdg_sw2d_curved_exchange(bdg_sw2d_curved* s, int which);
+int bdg_sw2d_curved_barrier(bdg_sw2d_curved* s);
 size_t bdg_sw2d_curved_device_bytes(const bdg_sw2d_curved* s);
 /* Compulsory HBM bytes of one RHS evaluation with the tables as this solver holds them (per element, averaged). */
 double bdg_sw2d_curved_bytes_per_element(const bdg_sw2d_curved* s);

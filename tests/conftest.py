@@ -194,3 +194,16 @@ def variant_b_setup(order, mesh, seed=3):
     hv = 0.8 * rng.standard_normal(x.shape)
     extras = dict(mapO=mapO, H=H, h=h, hu=hu, hv=hv, CD=2.5e-3, f=1.0070e-4, time=0.37 * 3600 * 12.42)
     return nodes, t, extras
+
+
+@pytest.fixture(scope="session")
+def mock_rccl(tmp_path_factory):
+    """A file-based stand-in for librccl.so (tests/mock_rccl: the nine entry points the library binds), so that the ranks of a
+    multi-process test can share the single GPU of a test box, which RCCL itself refuses: the environment a rank needs."""
+    out = tmp_path_factory.mktemp("mock_rccl")
+    lib = out / "libmock_rccl.so"
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-fPIC", "-shared", "--offload-arch=gfx950", "-I/opt/rocm/include",
+           os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), "-o", str(lib)]
+    build = launch(cmd, timeout=600)
+    assert build.returncode == 0, build.stderr[-3000:]
+    return {"BDG_RCCL_LIBRARY": str(lib), "BDG_MOCK_RCCL_DIR": str(out)}

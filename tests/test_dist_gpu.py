@@ -280,15 +280,7 @@ def test_loopback_rccl_result_is_independent_of_event_flags_and_halo_staging(ord
 # ---- the real multi-process path (one process per rank, the library's own communicator and stage loop) with a
 # ---- file-based stand-in for librccl.so, so that the ranks can share the single GPU of a test box
 
-@pytest.fixture(scope="module")
-def mock_rccl(tmp_path_factory):
-    out = tmp_path_factory.mktemp("mock_rccl")
-    lib = out / "libmock_rccl.so"
-    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O2", "-fPIC", "-shared", "--offload-arch=gfx950", "-I/opt/rocm/include",
-           os.path.join(ROOT, "tests", "mock_rccl", "mock_rccl.cpp"), "-o", str(lib)]
-    build = launch(cmd, timeout=600)
-    assert build.returncode == 0, build.stderr[-3000:]
-    return {"BDG_RCCL_LIBRARY": str(lib), "BDG_MOCK_RCCL_DIR": str(out)}
+# (fixture mock_rccl: tests/conftest.py)
 
 
 def _native_worker(rank, world, port, env, out_dir, order=ORDER, strip="throughput"):

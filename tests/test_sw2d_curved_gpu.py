@@ -261,41 +261,56 @@ def _dist_sources(x, y):
     return {"zx": 0.05 + 0 * x, "zy": -0.04 * y, "f": 0.0788, "CD": 2.5e-3 * (1.0 + 0.5 * np.cos(x))}
 
 
-def _curved_rank_worker(rank, world, port, out_dir, general):
+def _curved_rank_worker(rank, world, port, out_dir, general, native_env=None):
     import sys
-    import torch.distributed as dist
     from blitzdg_amd.halo import build_plan
-    from blitzdg_amd.sw2d_curved import DistributedSw2dCurved
+    from blitzdg_amd.sw2d_curved import DistributedSw2dCurved, NativeDistributedSw2dCurved
     if general:
         os.environ["BDG_SW2D_CURVED_GENERAL"] = "1"
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*DIST_MESH, shuffleSeed=5)
+    mesh.partitionMesh(world)
+    plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, rank, world, bctype=mesh.bcType)
+    kw = dict(g=0.0245, filter_args=(0.9 * DIST_ORDER, DIST_ORDER), sources=_dist_sources)
+    dist = None
+    if native_env is not None:     # the library's own exchange (pack kernel, grouped send / receive, unpack kernel) through tests/mock_rccl
+        os.environ.update(native_env)
+        os.environ.update({"RANK": str(rank), "LOCAL_RANK": "0", "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1",
+                           "MASTER_PORT": str(port)})
+        d = NativeDistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, **kw)
+        assert "torch" not in sys.modules
+    else:
+        import torch.distributed as dist
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        d = DistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, dist, **kw)
     try:
-        mesh = dg.MeshManager()
-        mesh.buildBoxMesh(*DIST_MESH, shuffleSeed=5)
-        mesh.partitionMesh(world)
-        plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, rank, world, bctype=mesh.bcType)
-        d = DistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, dist, g=0.0245, filter_args=(0.9 * DIST_ORDER, DIST_ORDER),
-                                  sources=_dist_sources)
         d.set_initial_state(_dist_state)
-        d.step_rk2(DIST_DT, DIST_STEPS)
+        d.step_rk2(DIST_DT, 1)                # several calls
+        d.step_rk2(DIST_DT, DIST_STEPS - 1)
         out = d.owned_state()
+        if native_env is not None:
+            d.barrier()
         np.savez(os.path.join(out_dir, f"curved{rank}.npz"), ids=out[0], ghosts=plan.num_halo, **{f"q{i}": a for i, a in enumerate(out[1:])})
     finally:
-        dist.destroy_process_group()
+        if dist is not None:
+            dist.destroy_process_group()
     sys.stdout.flush()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world, form):
-    """DistributedSw2dCurved: each rank owns a part of a deformed, shuffled box mesh plus a ghost layer, refreshes the ghost
-    columns before every RHS evaluation (gloo) and runs the driver's RK2 + filter steps; the owned states equal the
-    single-domain solver's to round-off (the tiling of the elements differs between the runs, so not bit for bit)."""
+@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (2, "native"), (3, "native")])
+def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world, transport, form, mock_rccl):
+    """DistributedSw2dCurved / NativeDistributedSw2dCurved: each rank owns a part of a deformed, shuffled box mesh plus a ghost
+    layer, refreshes the ghost columns before every RHS evaluation -- host-staged over gloo, or by the library itself
+    (bdg_sw2d_curved_comm_init / _step_rk2_exchanged: pack kernel, grouped send / receive, unpack kernel, with only librccl.so
+    replaced by tests/mock_rccl) -- and runs the driver's RK2 + filter steps; the owned states equal the single-domain solver's to
+    round-off (the tiling of the elements differs between the runs, so not bit for bit)."""
     import socket
     from conftest import launch_ranks
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    launch_ranks("test_sw2d_curved_gpu", "_curved_rank_worker", world, (world, port, str(tmp_path), form == "general"))
+    launch_ranks("test_sw2d_curved_gpu", "_curved_rank_worker", world,
+                 (world, port, str(tmp_path), form == "general", mock_rccl if transport == "native" else None))
     mesh = dg.MeshManager()
     mesh.buildBoxMesh(*DIST_MESH, shuffleSeed=5)
     nodes = dg.TriangleNodesProvisioner(DIST_ORDER, mesh)
@@ -321,6 +336,47 @@ def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world
             assert np.abs(p[f"q{i}"] - full[:, p["ids"]]).max() <= STATE_TOL * np.abs(full).max(), f"field {i} differs on rank {r}"
     assert (seen == 1).all() and 0 < curved.size < mesh.numElements
     assert np.abs(ref[1] - q0[1]).max() > 1e-5                   # the state did move
+
+
+def test_native_curved_exchange_through_real_rccl_loopback():
+    """The library's exchange through the REAL librccl.so on this one GPU: rank 0's share of a 2-way split with every neighbour
+    exchange a send-to-self (NativeDistributedSw2dCurved(loopback=True)): pack kernel, ncclSend / ncclRecv to the own rank, unpack
+    kernel. The ghosts then hold this rank's own boundary elements; the same copies done by hand through the host-staged
+    interface (get / set elements, rk2Phase) must give the same state bit for bit."""
+    from blitzdg_amd.halo import build_plan
+    from blitzdg_amd.sw2d_curved import DistributedSw2dCurved, NativeDistributedSw2dCurved
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*DIST_MESH)
+    mesh.partitionMesh(2)
+    plan = build_plan(mesh.elements, mesh.vertices, mesh.EToE, mesh.elementPartitionMap, 0, 2, bctype=mesh.bcType)
+    kw = dict(g=0.0245, filter_args=(0.9 * DIST_ORDER, DIST_ORDER), sources=_dist_sources)
+    nat = NativeDistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, loopback=True, **kw)
+    pr, ss, sc, rs, rc = nat.peer_table
+    if int(rc.sum()) != plan.num_halo:
+        pytest.skip("this split has a neighbour that sends fewer elements than it receives: a self-exchange leaves ghosts unset")
+    nat.set_initial_state(_dist_state)
+    nat.step_rk2(DIST_DT, 3)
+    nat.barrier()
+    got = nat.solver.getState()
+
+    class ByHand(DistributedSw2dCurved):
+        def _exchange(self, intermediate):
+            n_own = self.plan.num_owned
+            for s0, cnt, r0 in zip(ss, sc, rs):
+                for i in range(int(cnt)):
+                    col = self.solver.getElements(int(self.plan.send_local[s0 + i]), 1, intermediate)
+                    self.solver.setElements(n_own + int(r0) + i, col, intermediate)
+
+    class _NoDist:
+        @staticmethod
+        def get_backend():
+            return "none"
+    ref = ByHand(plan, DIST_ORDER, _dist_deform, _NoDist(), **kw)
+    ref.set_initial_state(_dist_state)
+    ref.step_rk2(DIST_DT, 3)
+    want = ref.solver.getState()
+    for a, b in zip(got, want):
+        assert np.isfinite(b).all() and np.array_equal(a, b)
 
 
 def test_bad_tables_are_refused_before_anything_runs():
