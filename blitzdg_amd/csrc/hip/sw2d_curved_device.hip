@@ -115,14 +115,25 @@ struct bdg_sw2d_curved {
     // partitioned runs (bdg_sw2d_curved_set_partition / _comm_init): elements [numOwned, K) are ghosts, refreshed from their
     // owners before every evaluation by grouped ncclSend / ncclRecv on the solver's stream
     struct Peer { int rank, sendStart, sendCount, recvStart, recvCount; };
-    int numOwned = 0, numSend = 0, commRank = 0, commWorld = 1;
+    int numOwned = 0, numInterior = 0, numSend = 0, commRank = 0, commWorld = 1;
     Buf<int> sendEls;
-    Buf<double> sendBuf, recvBuf;
+    // overlapped schedule (nodal-trace form): elements [0, numInterior) have no ghost neighbour and are evaluated on the solver's
+    // stream while the exchange and then the partition-boundary elements [numInterior, numOwned) run on commStream; the curved
+    // elements of the two ranges (columns of the side buffer) are listed for the fix-up launches of either chain
+    std::vector<int> curvedHost;          // element of each side-buffer column
+    Buf<int> slotsInterior, slotsBoundary;
+    int numSlotsInterior = 0, numSlotsBoundary = 0;
+    hipStream_t commStream = nullptr;
+    hipEvent_t evA[2] = {nullptr, nullptr}, evB[2] = {nullptr, nullptr}, evEntry = nullptr;
+    Buf<double> sendBuf, recvBuf, scalarBuf;
     std::vector<Peer> peers;
     ncclComm_t comm = nullptr;
 
     ~bdg_sw2d_curved() {
         if (comm) (void)bdg_rccl::rccl().CommDestroy(comm);
+        for (hipEvent_t e : {evA[0], evA[1], evB[0], evB[1], evEntry})
+            if (e) (void)hipEventDestroy(e);
+        if (commStream) (void)hipStreamDestroy(commStream);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -165,6 +176,20 @@ struct bdg_sw2d_curved {
     }
 
     // One RHS evaluation fused with its update: Gauss traces of qin, stage kernel, curved-element kernel.
+    // the same for the elements [kbegin, kend) and the listed columns of the side buffer only, on a given stream (nodal-trace form)
+    void evaluateRange(int mode, bool filter, const double* qin, const double* qbase, double* qout, double ca, double cb, double cc,
+                       int kbegin, int kend, const int* slotList, int numSlots, hipStream_t on, int gridReserve = 0) {
+        if (filter && !hasFilter) throw arg_error("bdg_sw2d_curved: filter requested but the solver was created without a Filter matrix");
+        if (!useNT || qin == qout) throw arg_error("bdg_sw2d_curved: range evaluations need the nodal-trace form and two state buffers");
+        bdg_dev::CurvedParams p = params();
+        p.qin = qin; p.qbase = qbase; p.qout = qout; p.res = res.p; p.rhs = rhs.p; p.ca = ca; p.cb = cb; p.cc = cc;
+        p.kbegin = kbegin; p.K = kend; p.gridReserve = gridReserve;
+        p.tileOrder = nullptr;  // (the list is built for the tiles of [0, K))
+        hipOk(kt->stageNT(mode, filter, p, on), "sw2d_curved_nt_kernel");
+        p.slotList = slotList; p.numCurved = numSlots;
+        hipOk(kt->fixup(mode, filter, p, on), "sw2d_curved_fixup_kernel");
+    }
+
     void evaluate(int mode, bool filter, const double* qin, const double* qbase, double* qout, double ca, double cb,
                   double cc) {
         if (filter && !hasFilter) throw arg_error("bdg_sw2d_curved: filter requested but the solver was created without a Filter matrix");
@@ -193,7 +218,8 @@ struct bdg_sw2d_curved {
     }
 
     // ghost columns of `state` from their owners (pack -> grouped send / receive with every neighbour -> unpack), in stream order
-    void exchange(double* state) {
+    void exchange(double* state) { exchangeOn(state, stream); }
+    void exchangeOn(double* state, hipStream_t stream) {
         if (!comm) throw arg_error("bdg_sw2d_curved: no communicator (call bdg_sw2d_curved_comm_init first)");
         const int rows = 4 * Np, ghosts = K - numOwned;
         if (numSend > 0) {
@@ -223,13 +249,55 @@ struct bdg_sw2d_curved {
         }
     }
     // the driver's RK2 step of a partitioned run: an exchange in front of EACH evaluation, of the state that evaluation reads
+    //
+    // Nodal-trace form with interior elements: two chains, as the straight-element solver's stage loop (sw2d_device.hip):
+    //   solver stream A:  wait B(e-1) -> [elements without a ghost neighbour of evaluation e] -> signal A(e)
+    //   comm stream   B:  wait A(e-1) -> pack, grouped send / receive, unpack of the state e reads -> [partition-boundary
+    //                     elements of e] -> signal B(e)
+    // interior(e) reads the boundary elements' columns boundary(e-1) wrote and overwrites columns boundary(e-1) read: it waits
+    // for B(e-1); boundary(e) and its pack read / overwrite columns interior(e-1) wrote / read: B waits for A(e-1). Ghost
+    // columns are written by the unpack and read by the boundary launch only, both on B. Ghost elements are not evaluated.
+    // Otherwise (general form, or no interior elements): exchange, then every element, in stream order.
     void stepRk2Exchanged(double dt, int steps, bool filter) {
-        for (int i = 0; i < steps; ++i) {
-            exchange(qA.p);
-            evaluate(bdg_dev::CMODE_COMBINE, filter, qA.p, qA.p, qB.p, 1.0, 0.0, 0.5 * dt);
-            exchange(qB.p);
-            evaluate(bdg_dev::CMODE_COMBINE, filter, qB.p, qA.p, qA.p, 1.0, 0.0, dt);
+        const bool noOverlap = std::getenv("BDG_SW2D_CURVED_NO_OVERLAP") != nullptr; // (A/B switch, read per call)
+        if (!useNT || numInterior < 1 || noOverlap) {
+            for (int i = 0; i < steps; ++i) {
+                exchange(qA.p);
+                evaluate(bdg_dev::CMODE_COMBINE, filter, qA.p, qA.p, qB.p, 1.0, 0.0, 0.5 * dt);
+                exchange(qB.p);
+                evaluate(bdg_dev::CMODE_COMBINE, filter, qB.p, qA.p, qA.p, 1.0, 0.0, dt);
+            }
+            return;
         }
+        hipOk(hipEventRecord(evEntry, stream), "hipEventRecord");          // whatever set the state, on A
+        hipOk(hipStreamWaitEvent(commStream, evEntry, 0), "hipStreamWaitEvent");
+        bool haveA = false, haveB = false;
+        int e = 0;
+        // the interior launch is one resident round of workgroups that loop over their tiles: it leaves the slots the
+        // partition-boundary launch needs (a workgroup per four tiles, rounded up to the eight XCDs), or that launch would wait
+        const int boundaryWgs = (((numOwned - numInterior + 15) / 16 + 3) / 4 + 7) / 8 * 8;
+        for (int i = 0; i < steps; ++i)
+            for (int ph = 0; ph < 2; ++ph, ++e) {
+                double* in = ph == 0 ? qA.p : qB.p;
+                double* out = ph == 0 ? qB.p : qA.p;
+                const double cc = ph == 0 ? 0.5 * dt : dt;
+                const int cur = e & 1, prev = cur ^ 1;
+                // ---- chain A
+                if (haveB) hipOk(hipStreamWaitEvent(stream, evB[prev], 0), "hipStreamWaitEvent");
+                evaluateRange(bdg_dev::CMODE_COMBINE, filter, in, qA.p, out, 1.0, 0.0, cc, 0, numInterior, slotsInterior.p, numSlotsInterior, stream,
+                              boundaryWgs);
+                hipOk(hipEventRecord(evA[cur], stream), "hipEventRecord");
+                // ---- chain B
+                if (haveA) hipOk(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
+                exchangeOn(in, commStream);
+                evaluateRange(bdg_dev::CMODE_COMBINE, filter, in, qA.p, out, 1.0, 0.0, cc, numInterior, numOwned, slotsBoundary.p, numSlotsBoundary,
+                              commStream);
+                hipOk(hipEventRecord(evB[cur], commStream), "hipEventRecord");
+                haveA = haveB = true;
+            }
+        // join both ways: later work on A sees the last boundary update, later work on B the last interior launch
+        hipOk(hipStreamWaitEvent(stream, evB[(e - 1) & 1], 0), "hipStreamWaitEvent");
+        hipOk(hipStreamWaitEvent(commStream, evA[(e - 1) & 1], 0), "hipStreamWaitEvent");
     }
     void stepRk2(double dt, int steps, bool filter) {
         for (int i = 0; i < steps; ++i) {
@@ -701,6 +769,7 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
         std::vector<int> slots(static_cast<size_t>(ld), -1);
         std::copy(slotOf.begin(), slotOf.end(), slots.begin());
         hipOk(hipMemcpyAsync(s->curvedSlot.p, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice, st), "slot upload");
+        s->curvedHost = curved;
         s->curvedEls.alloc(curved.size(), s->bytes, st);
         hipOk(hipMemcpyAsync(s->curvedEls.p, curved.data(), curved.size() * sizeof(int), hipMemcpyHostToDevice, st), "curvedEls upload");
         // inverse mass matrix of every listed element from its upper Cholesky factor U (M = U^T U): W = U^-1 by back
@@ -836,6 +905,7 @@ int bdg_sw2d_curved_create(const bdg_sw2d_curved_desc* desc, bdg_sw2d_curved** o
 void bdg_sw2d_curved_destroy(bdg_sw2d_curved* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    if (s->commStream) (void)hipStreamSynchronize(s->commStream);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     delete s;
 }
@@ -959,10 +1029,11 @@ int bdg_sw2d_curved_rk2_phase(bdg_sw2d_curved* s, double dt, int phase, int filt
     });
 }
 
-int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_owned, const int* send_elements, int num_send) {
+int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_interior, int num_owned, const int* send_elements, int num_send) {
     return guard([&] {
         requireCurved(s, "bdg_sw2d_curved_set_partition");
-        if (num_owned < 1 || num_owned > s->K || num_send < 0 || (num_send > 0 && !send_elements))
+        if (num_owned < 1 || num_owned > s->K || num_interior < 0 || num_interior > num_owned || num_send < 0 ||
+            (num_send > 0 && !send_elements))
             throw arg_error("bdg_sw2d_curved_set_partition: bad argument");
         for (int i = 0; i < num_send; ++i)
             if (send_elements[i] < 0 || send_elements[i] >= num_owned)
@@ -970,7 +1041,23 @@ int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_owned, const int* 
         if (s->comm) throw arg_error("bdg_sw2d_curved_set_partition: the communicator is already initialised");
         s->use();
         s->numOwned = num_owned;
+        s->numInterior = num_interior;
         s->numSend = num_send;
+        std::vector<int> inner, outer; // columns of the side buffer whose element is an interior / a partition-boundary one
+        for (size_t c = 0; c < s->curvedHost.size(); ++c) {
+            const int k = s->curvedHost[c];
+            if (k < num_interior) inner.push_back(static_cast<int>(c));
+            else if (k < num_owned) outer.push_back(static_cast<int>(c));
+        }
+        s->numSlotsInterior = static_cast<int>(inner.size());
+        s->numSlotsBoundary = static_cast<int>(outer.size());
+        s->slotsInterior.alloc(std::max<size_t>(1, inner.size()), s->bytes, s->stream);
+        s->slotsBoundary.alloc(std::max<size_t>(1, outer.size()), s->bytes, s->stream);
+        if (!inner.empty())
+            hipOk(hipMemcpyAsync(s->slotsInterior.p, inner.data(), inner.size() * sizeof(int), hipMemcpyHostToDevice, s->stream), "slot list upload");
+        if (!outer.empty())
+            hipOk(hipMemcpyAsync(s->slotsBoundary.p, outer.data(), outer.size() * sizeof(int), hipMemcpyHostToDevice, s->stream), "slot list upload");
+        hipOk(hipStreamSynchronize(s->stream), "slot list sync"); // (inner, outer are locals)
         s->sendEls.alloc(static_cast<size_t>(std::max(1, num_send)), s->bytes, s->stream);
         if (num_send > 0)
             hipOk(hipMemcpyAsync(s->sendEls.p, send_elements, static_cast<size_t>(num_send) * sizeof(int), hipMemcpyHostToDevice, s->stream),
@@ -1005,9 +1092,14 @@ int bdg_sw2d_curved_comm_init(bdg_sw2d_curved* s, int rank, int world, const voi
         s->commRank = rank;
         s->commWorld = world;
         s->peers = peers;
+        hipOk(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
+        // (events that only order kernels of this device's two streams: no system-scope fence, as in bdg_sw2d_comm_init)
+        for (hipEvent_t* e : {&s->evA[0], &s->evA[1], &s->evB[0], &s->evB[1], &s->evEntry})
+            hipOk(hipEventCreateWithFlags(e, hipEventDisableTiming | hipEventDisableSystemFence), "hipEventCreate");
         const size_t rows = static_cast<size_t>(4) * s->Np;
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes, s->stream);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes, s->stream);
+        s->scalarBuf.alloc(2, s->bytes, s->stream);
         hipOk(hipStreamSynchronize(s->stream), "exchange buffers");
     });
 }
@@ -1034,9 +1126,9 @@ int bdg_sw2d_curved_barrier(bdg_sw2d_curved* s) {
         requireCurved(s, "bdg_sw2d_curved_barrier");
         if (!s->comm) throw arg_error("bdg_sw2d_curved_barrier: no communicator");
         s->use();
+        hipOk(hipStreamSynchronize(s->commStream), "hipStreamSynchronize");
         hipOk(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
-        double* scratch = s->sendBuf.p; // (idle between exchanges; one double is all the reduction touches)
-        bdg_rccl::ncclCheck(bdg_rccl::rccl().AllReduce(scratch, scratch, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce");
+        bdg_rccl::ncclCheck(bdg_rccl::rccl().AllReduce(s->scalarBuf.p, s->scalarBuf.p, 1, ncclDouble, ncclMax, s->comm, s->stream), "ncclAllReduce");
         hipOk(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
     });
 }

@@ -63,7 +63,8 @@ struct CurvedParams {
     double* mmSide;        // (numCurved, 4, Np): raw MM_c of the elements of curvedEls
     const double* minvSide; // (numCurved, Np, Np): their inverse mass matrices U^-1 U^-T (from cub_ctx.MMChol)
     const int* curvedEls;  // element slot of each side-buffer column
-    int numCurved;
+    int numCurved;          // columns of the side buffer the fix-up launch works on
+    const int* slotList;    // nullptr: columns 0 .. numCurved - 1; else column slotList[i] (partitioned runs: the curved elements of a range)
     long long sideLd;
     const int* affineEl;    // ld: 1 for straight-sided elements whose cubature geometry is held compressed (nullptr: none)
     const double* cubAffine; // 4 rows of ld: the element's numbers c with (W rx, W ry, W sx, W sy)[i] = cubWref[i] * c
@@ -83,7 +84,9 @@ struct CurvedParams {
                              // general (not all straight-sided) tiles: they cost more, and meshes keep them together
     const double* filt;   // (Np, Np) row-major filter for the fix-up kernel, or nullptr
     long long ld;
-    int K;
+    int K;                // elements [kbegin, K) are worked on by the nodal-trace launch (kbegin = 0 in the first form)
+    int kbegin;
+    int gridReserve;      // nodal-trace launch: workgroup slots of the chip left free (for the launch that runs beside it)
     int ncb;              // 16-row blocks of cubature points
     int ncub;             // cubature points
     int ng;               // Gauss points per face
@@ -578,7 +581,8 @@ __global__ __launch_bounds__(64) void sw2d_curved_fixup_kernel(const CurvedParam
     const int lane = static_cast<int>(threadIdx.x), e = lane / P, i = lane % P, first = e * P;
     const int slotTrue = static_cast<int>(blockIdx.x) * EPW + e;
     const bool has = slotTrue < p.numCurved, mine = has && i < Np;
-    const int slot = has ? slotTrue : p.numCurved - 1, ic = i < Np ? i : Np - 1; // (clamped: every lane reads valid memory)
+    const int col = has ? slotTrue : p.numCurved - 1, ic = i < Np ? i : Np - 1; // (clamped: every lane reads valid memory)
+    const int slot = p.slotList ? p.slotList[col] : col;
     const unsigned k = static_cast<unsigned>(p.curvedEls[slot]), k8 = k * 8u;
     const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
     const double* __restrict__ Mi = p.minvSide + static_cast<size_t>(slot) * Np * Np;

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
     const unsigned soZx = p.zx ? static_cast<unsigned>((p.zx - p.rJ) * 8) : 0u, soZy = p.zy ? static_cast<unsigned>((p.zy - p.rJ) * 8) : 0u,
                    soFc = p.fcor ? static_cast<unsigned>((p.fcor - p.rJ) * 8) : 0u, soCd = p.cd ? static_cast<unsigned>((p.cd - p.rJ) * 8) : 0u;
     const double g = p.g;
-    const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u;
+    const unsigned ntiles = (static_cast<unsigned>(p.K - p.kbegin) + 15u) / 16u; // tiles of the element range [kbegin, K)
     // Tiles of this wave. XCD x (workgroups b with b mod 8 = x share its L2) owns one contiguous eighth of the tiles; its waves
     // take them SIDE BY SIDE (wave w of W: tiles w, w + W, ...), so that what an XCD holds at any time is a compact patch of
     // the mesh and the neighbours' face nodes a tile gathers are rows a sibling wave is streaming (p.tileInterleave = 0: one
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, WAVES) void sw2d_curved_nt_kernel(const Curved
         if (prio == 1) __builtin_amdgcn_s_setprio(1);
         if (prio == 2) __builtin_amdgcn_s_setprio(0);
         const unsigned tile = (order && act) ? static_cast<unsigned>(__builtin_amdgcn_readfirstlane(order[pos])) : pos;
-        const unsigned kTrue = tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
+        const unsigned kTrue = static_cast<unsigned>(p.kbegin) + tile * 16u + j, kLast = static_cast<unsigned>(p.K) - 1u;
         const bool live = act && kTrue <= kLast;
         const unsigned k = (act && kTrue <= kLast) ? kTrue : kLast; // padding lanes recompute the last element, store nothing
         const unsigned k8 = k * 8u, v8 = (q * static_cast<unsigned>(ld) + k) * 8u, v4 = v8 >> 1;

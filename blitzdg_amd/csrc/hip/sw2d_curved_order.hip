@@ -150,11 +150,13 @@ hipError_t launchNT(const CurvedParams& p, hipStream_t stream, size_t lds) {
     }
     // resident workgroups: WAVES per SIMD = WAVES workgroups of four waves per CU, as far as LDS allows
     const int wgPerCu = std::max(1, std::min<int>(WAVES, static_cast<int>(kLdsLimitBytes / std::max<size_t>(lds, 1))));
-    const unsigned ntiles = (static_cast<unsigned>(p.K) + 15u) / 16u, wgs = (ntiles + 3u) / 4u;
+    const unsigned ntiles = (static_cast<unsigned>(p.K - p.kbegin) + 15u) / 16u, wgs = (ntiles + 3u) / 4u;
     static const unsigned rounds = [] { const char* e = std::getenv("BDG_SW2D_CURVED_ROUNDS"); return e ? static_cast<unsigned>(std::atoi(e)) : 0u; }();
     // one resident round of workgroups (each wave loops over its tiles): a second round re-stages the operator image and balances
     // no better (BDG_SW2D_CURVED_ROUNDS=2..4 measured 1-4 % slower at N = 3, 6, 8)
-    const unsigned grid = std::max(1u, std::min(wgs, 256u * static_cast<unsigned>(wgPerCu) * (rounds ? rounds : 1u)));
+    const unsigned slots = 256u * static_cast<unsigned>(wgPerCu) * (rounds ? rounds : 1u);
+    const unsigned reserve = std::min(static_cast<unsigned>(std::max(p.gridReserve, 0)), slots / 2u);
+    const unsigned grid = std::max(1u, std::min(wgs, slots - reserve));
 #ifdef BDG_PHASE_CLOCK
     // profiling build: the per-wave phase cycles of the last launch (workgroups 0..1023) go to $BDG_PHASE_CLOCK_FILE when the
     // process exits (pinned host memory the kernel writes directly, so nothing of HIP is needed at that point)
@@ -199,7 +201,7 @@ hipError_t launchShape(const CurvedParams& p, hipStream_t stream, size_t lds) {
 
 template <int MODE, bool FILTER>
 hipError_t launchStageNT(const CurvedParams& p, hipStream_t stream) {
-    if (p.K < 1) return hipSuccess;
+    if (p.K <= p.kbegin) return hipSuccess;
     const bool streamed = ntStreamed(p.ncb, p.fb);
     const size_t lds = streamed ? ntLdsStreamed(p.ncb, p.fb, FILTER) : ntLdsResident(p.ncb, p.fb);
     if (lds > kLdsLimitBytes || p.fb < 1 || p.fb > 2) return hipErrorInvalidValue; // (ntFits was asked at creation)

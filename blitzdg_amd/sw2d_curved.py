@@ -223,7 +223,7 @@ class NativeDistributedSw2dCurved(DistributedSw2dCurved):
     """DistributedSw2dCurved with the ghost exchange driven by the C++ library: pack kernel, grouped ncclSend / ncclRecv with
     every neighbour on the solver's stream, unpack kernel -- device to device over RCCL (xGMI), whole step loops in one C call,
     no PyTorch. One process per rank; rank 0's RCCL id reaches the others through halo.file_rendezvous (or pass unique_id).
-    Not overlapped with the evaluation: every element of the nodal-trace kernel may gather from a ghost column."""
+    On the nodal-trace form the elements without a ghost neighbour are evaluated beside the exchange (two streams)."""
 
     def __init__(self, plan, order, deform, g=9.81, filter_args=None, sources=None, device=0, unique_id=None, loopback=False):
         """loopback=True: this one process computes plan.rank's share of a plan.world-way split and every neighbour exchange
@@ -242,7 +242,7 @@ class NativeDistributedSw2dCurved(DistributedSw2dCurved):
         super().__init__(plan, order, deform, _NoDist(), g=g, filter_args=filter_args, sources=sources, device=device)
         h = self.solver._h
         send = np.ascontiguousarray(plan.send_local, dtype=np.int32)
-        check(lib.bdg_sw2d_curved_set_partition(h, plan.num_owned, ptr(send), send.size))
+        check(lib.bdg_sw2d_curved_set_partition(h, plan.num_interior, plan.num_owned, ptr(send), send.size))
         id_path = None
         comm_rank, comm_world = plan.rank, plan.world
 

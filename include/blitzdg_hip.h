@@ -467,13 +467,16 @@ int bdg_sw2d_curved_set_elements(bdg_sw2d_curved* s, int which, int first, int c
  * phase 0 -- predictor, intermediate = state + dt/2 RHS(state); phase 1 -- corrector, state += dt RHS(intermediate). */
 int bdg_sw2d_curved_rk2_phase(bdg_sw2d_curved* s, double dt, int phase, int filter);
 /* The same exchange driven by this library over RCCL (point-to-point over xGMI; bound with dlopen on first use, as for
- * bdg_sw2d_comm_init, whose id -- bdg_comm_unique_id -- and neighbour tables it takes): elements [num_owned, K) of the solver's
- * mesh are ghosts; peer i is sent the elements send_elements[send_start[i] .. + send_count[i]) and its recv_count[i] elements
- * arrive in ghost slots recv_start[i] .. (relative to num_owned); one record of 4 Np doubles per element. step_rk2_exchanged =
- * num_steps times {exchange(state), predictor, exchange(intermediate), corrector}, all in stream order on the device (not
- * overlapped with the evaluation: every element of the nodal-trace kernel may gather from a ghost). exchange: one refresh by
- * itself (which as above). barrier: drains the stream, meets every rank (an 8-byte all-reduce), drains again. */
-int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_owned, const int* send_elements, int num_send);
+ * bdg_sw2d_comm_init, whose id -- bdg_comm_unique_id -- and neighbour tables it takes): the solver's mesh is ordered
+ * [elements without a ghost neighbour: num_interior | partition-boundary elements: up to num_owned | ghosts: up to K]; peer i is
+ * sent the elements send_elements[send_start[i] .. + send_count[i]) and its recv_count[i] elements arrive in ghost slots
+ * recv_start[i] .. (relative to num_owned); one record of 4 Np doubles per element. step_rk2_exchanged = num_steps times
+ * {exchange(state), predictor, exchange(intermediate), corrector}; on the nodal-trace form the interior elements of an
+ * evaluation run on the solver's stream beside the exchange and the partition-boundary elements on a second stream (two chains
+ * joined by events, as bdg_sw2d_lserk4_stages_exchanged), ghost elements are not evaluated, and the ghost columns bdg_sw2d_curved_
+ * get_state returns afterwards are whatever was last received. exchange: one refresh by itself (which as above). barrier: drains
+ * the streams, meets every rank (an 8-byte all-reduce), drains again. */
+int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_interior, int num_owned, const int* send_elements, int num_send);
 int bdg_sw2d_curved_comm_init(bdg_sw2d_curved* s, int rank, int world, const void* unique_id, const int* peer_ranks,
                               const int* send_start, const int* send_count, const int* recv_start, const int* recv_count,
                               int num_peers);

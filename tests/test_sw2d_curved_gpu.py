@@ -338,11 +338,17 @@ def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world
     assert np.abs(ref[1] - q0[1]).max() > 1e-5                   # the state did move
 
 
-def test_native_curved_exchange_through_real_rccl_loopback():
+@pytest.mark.parametrize("overlap", [True, False])
+def test_native_curved_exchange_through_real_rccl_loopback(overlap, monkeypatch):
     """The library's exchange through the REAL librccl.so on this one GPU: rank 0's share of a 2-way split with every neighbour
     exchange a send-to-self (NativeDistributedSw2dCurved(loopback=True)): pack kernel, ncclSend / ncclRecv to the own rank, unpack
     kernel. The ghosts then hold this rank's own boundary elements; the same copies done by hand through the host-staged
-    interface (get / set elements, rk2Phase) must give the same state bit for bit."""
+    interface (get / set elements, rk2Phase) must give the same owned state -- bit for bit when every element is evaluated in
+    stream order (BDG_SW2D_CURVED_NO_OVERLAP), to round-off on the two-chain schedule of the nodal-trace form (interior and
+    partition-boundary elements are tiled separately there, and a straight element in a tile with a curved one takes the
+    general branch: other instructions, same function)."""
+    if not overlap:
+        monkeypatch.setenv("BDG_SW2D_CURVED_NO_OVERLAP", "1")
     from blitzdg_amd.halo import build_plan
     from blitzdg_amd.sw2d_curved import DistributedSw2dCurved, NativeDistributedSw2dCurved
     mesh = dg.MeshManager()
@@ -375,8 +381,14 @@ def test_native_curved_exchange_through_real_rccl_loopback():
     ref.set_initial_state(_dist_state)
     ref.step_rk2(DIST_DT, 3)
     want = ref.solver.getState()
+    n = plan.num_owned            # (ghost elements are not evaluated by the overlapped schedule: owned columns only)
+    assert 0 < plan.num_interior < n
     for a, b in zip(got, want):
-        assert np.isfinite(b).all() and np.array_equal(a, b)
+        assert np.isfinite(b[:, :n]).all()
+        if overlap and nat.solver.usesNodalTraces:
+            assert np.abs(a[:, :n] - b[:, :n]).max() <= STATE_TOL * np.abs(b).max()
+        else:
+            assert np.array_equal(a[:, :n], b[:, :n])
 
 
 def test_bad_tables_are_refused_before_anything_runs():
