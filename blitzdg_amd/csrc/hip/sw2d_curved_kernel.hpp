@@ -592,7 +592,15 @@ __global__ __launch_bounds__(64) void sw2d_curved_fixup_kernel(const CurvedParam
     // this node's state and source tables (requested with the matrix rows)
     const long long rowOff = static_cast<long long>(ic) * ld;
     const double h = cld_row(p.qin + rowOff, k8), hu = cld_row(p.qin + plane + rowOff, k8), hv = cld_row(p.qin + 2 * plane + rowOff, k8);
-#pragma unroll 5
+    // the rows the update reads, requested with everything else (this kernel is a few waves per SIMD of pure latency)
+    double own[4] = {h, hu, hv, 0.0}, old[4] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (MODE != CMODE_RHS) {
+        own[3] = cld_row(p.qin + 3 * plane + rowOff, k8);
+        const double* __restrict__ ob = MODE == CMODE_LSERK ? p.res : p.qbase;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) old[c] = cld_row(ob + c * plane + rowOff, k8);
+    }
+#pragma unroll 15
     for (int m = 0; m < Np; ++m) {
         const double a = Mi[m * Np + ic];
 #pragma unroll
@@ -625,11 +633,11 @@ __global__ __launch_bounds__(64) void sw2d_curved_fixup_kernel(const CurvedParam
         if constexpr (MODE == CMODE_RHS) {
             cst_row(p.rhs + off, k8, r[c]);
         } else if constexpr (MODE == CMODE_LSERK) {
-            const double n1 = p.ca * cld_row(p.res + off, k8) + p.cc * r[c];
+            const double n1 = p.ca * old[c] + p.cc * r[c];
             cst_row(p.res + off, k8, n1);
-            cst_row(p.qout + off, k8, cld_row(p.qin + off, k8) + p.cb * n1);
+            cst_row(p.qout + off, k8, own[c] + p.cb * n1);
         } else {
-            cst_row(p.qout + off, k8, p.ca * cld_row(p.qbase + off, k8) + p.cb * cld_row(p.qin + off, k8) + p.cc * r[c]);
+            cst_row(p.qout + off, k8, p.ca * old[c] + p.cb * own[c] + p.cc * r[c]);
         }
     }
 }
