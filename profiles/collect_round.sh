@@ -2,7 +2,7 @@
 # Everything else the round's profiles/ files are made of, in one gpurun call (bash profiles/collect_round.sh r03):
 # curved-solver timings of every order on both kernel forms, its PMC collections at N=4 / N=8, the 8-way rehearsal of
 # every matrix-core order with the whole-mesh time of the same box, a kernel timeline of the rehearsal, the step-kernel
-# timings of every variant. Raw output under gpurun_out/<tag>final/, PMC summaries under gpurun_out/summaries/.
+# timings of every variant, the loop-back rehearsal of the partitioned curved solver. Raw output under gpurun_out/<tag>final/, PMC summaries under gpurun_out/summaries/.
 set -uo pipefail
 TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -36,4 +36,7 @@ for n in 3 4 6 8; do
   cells=$([ $n -le 4 ] && echo 1000x500 || ([ $n = 6 ] && echo 1000x250 || echo 500x250))
   timeout -k 10 300 python3 profiles/time_rk2.py $n $cells 2>/dev/null | grep '^{'
 done > "$OUT/rk2_timings.jsonl"
+for cfg in "4 500 250 2" "4 500 250 4" "4 500 250 8" "6 300 200 4" "8 250 120 2"; do
+  timeout -k 10 300 python3 profiles/time_curved_rehearsal.py $cfg 1 50 2>/dev/null | grep '^{'
+done > "$OUT/curved_rehearsal.jsonl"
 ls -la "$OUT"

@@ -25,6 +25,12 @@ json.dump({"note": "ms per RHS evaluation of the curved / over-integrated solver
            "final": rows, "round2_kernels_on_reference_rules": keep}, open(old, "w"), indent=1)
 json.dump({"note": "ms per RHS evaluation of the fused step kernels (profiles/time_rk2.py), final sources of the round, one box",
            "orders": jsonl(os.path.join(O, "rk2_timings.jsonl"))}, open(os.path.join(P, f"{TAG}_rk2_timings.json"), "w"), indent=1)
+cr = jsonl(os.path.join(O, "curved_rehearsal.jsonl"))
+if cr:
+    json.dump({"note": "loop-back rehearsal of a partitioned run of the curved solver (profiles/time_curved_rehearsal.py): ONE GPU computes rank 1's "
+                       "share of a world-way split, every neighbour exchange a real RCCL send-to-self; ms per RHS evaluation on the two-chain schedule, "
+                       "with every element in stream order, and of the whole mesh on the same GPU", "runs": cr},
+              open(os.path.join(P, f"{TAG}_curved_rehearsal.json"), "w"), indent=1)
 for t in (f"{TAG}_curved_n4", f"{TAG}_curved_n8"):
     for suf in ("_pmc_summary.json", "_kernel_stats.csv"):
         src = os.path.join(R, "gpurun_out", "summaries", t + suf)
