@@ -109,6 +109,7 @@ struct bdg_sw2d_curved {
     Buf<double> opsNT, elAffine, gaussWref;
     Buf<int> nodeP, faceFlags, faceNodesDev, tileOrder;
     int numAffineNT = 0;
+    int prioMode = 2;   // see sw2d_curved_nt_kernel (BDG_SW2D_CURVED_PRIO at creation: A/B switch)
     double g = 9.81, fconst = 0.0, cdconst = 0.0;
     long long stageCount = 0;
     double bytesPerElement = 0.0;
@@ -169,7 +170,6 @@ struct bdg_sw2d_curved {
             static const int interleave = [] { const char* e = std::getenv("BDG_SW2D_TILE_INTERLEAVE"); return e ? std::atoi(e) : 1; }();
             p.tileInterleave = interleave;
             p.tileOrder = tileOrder.p;
-            static const int prioMode = [] { const char* e = std::getenv("BDG_SW2D_CURVED_PRIO"); return e ? std::atoi(e) : 2; }();
             p.prioMode = prioMode;
         }
         return p;
@@ -491,6 +491,7 @@ void buildNodalTraceTables(bdg_sw2d_curved& s, const bdg_sw2d_curved_desc& d, co
 
     // ---- order of the tiles: positions [n x / 8, n (x + 1) / 8) of the list are XCD x's (sw2d_curved_nt_kernel); each eighth gets
     //      an eighth of the general tiles (in mesh order, first), then straight-sided ones (in mesh order)
+    if (const char* e = std::getenv("BDG_SW2D_CURVED_PRIO")) s.prioMode = std::atoi(e);
     if (!std::getenv("BDG_SW2D_CURVED_NO_TILE_ORDER")) {
         const int ntiles = (K + 15) / 16;
         std::vector<int> general, straight, order;

@@ -391,6 +391,58 @@ def test_native_curved_exchange_through_real_rccl_loopback(overlap, monkeypatch)
             assert np.array_equal(a[:, :n], b[:, :n])
 
 
+@pytest.mark.parametrize("order,cells", [(2, (200, 100)), (4, (160, 100)), (7, (80, 48))])
+def test_full_launch_scheduling_does_not_change_the_result(order, cells, form, monkeypatch):
+    """What only a launch that fills the chip exercises (the fixtures are a few tiles): the list that deals the general tiles
+    to the eight XCDs, the priority window of a CU's second workgroup (N <= 4), the streamed volume tiles in lockstep (N = 7).
+    On a deformed box of 32 000 / 40 000 / 7 680 elements: the nodal-trace form with and without the tile list / the priority
+    agrees bit for bit (scheduling only), and with the general form -- other kernels, validated on the fixtures -- for one RHS
+    and after three RK2 + filter steps. Tolerance of that comparison: g = 9.81 on a fine mesh is a badly conditioned RHS (the
+    pressure term's volume and surface integrals are ~500 and cancel to ~5), and on straight-sided elements both forms replace
+    the builders' per-point metric tables -- constant up to their own round-off, ~1e-14 relative -- by one number per element
+    (differently: 14 numbers here, the cubature geometry only there), so the forms differ by that noise times the
+    conditioning: measured 2e-11 .. 1e-10 of max|RHS| on straight elements (against the NumPy restatement on the noisy
+    tables: 1.7e-11 and 6e-12), 2.6e-13 on the curved ones; bound asserted: 5e-10."""
+    if form == "general":
+        pytest.skip("one comparison of the two forms is enough")
+
+    def run(env):
+        for k in ("BDG_SW2D_CURVED_GENERAL", "BDG_SW2D_CURVED_NO_TILE_ORDER", "BDG_SW2D_CURVED_PRIO"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        mesh = dg.MeshManager()
+        mesh.buildBoxMesh(*cells)
+        nodes = dg.TriangleNodesProvisioner(order, mesh)
+        nodes.buildFilter(0.9 * order, order)
+        ctx = nodes.dgContext()
+        x0, y0 = ctx.x, ctx.y
+        blend = np.clip(1.0 - (y0 + 1.0) / 0.15, 0.0, 1.0) ** 3
+        x, y = x0 + 0.004 * blend * np.sin(2 * y0 + 1), y0 + 0.02 * blend * np.sin(3 * x0)
+        curved = np.where((np.abs(x - x0) + np.abs(y - y0)).max(axis=0) > 0)[0]
+        nodes.setCoordinates(x, y)
+        J = (ctx.Dr @ x) * (ctx.Ds @ y) - (ctx.Ds @ x) * (ctx.Dr @ y)
+        gauss, cub = nodes.buildGaussFaceNodes(2 * (order + 1)), nodes.buildCubatureVolumeMesh(3 * (order + 1))
+        s = Sw2dCurvedSolver(ctx, cub, gauss, curved, J, gauss.mapM, gauss.mapP, g=9.81, zx=0.01 * np.cos(x), zy=0.02 * np.sin(y),
+                             f=0.3, CD=2.5e-3 * (1.0 + 0.5 * np.cos(x)))
+        h = 1.0 + 0.1 * np.exp(-10 * x * x - 10 * (y + 0.5) ** 2)
+        q = (h, 0.05 * h * np.sin(3 * x), 0.04 * h * np.cos(2 * y), h * (0.5 + 0.3 * np.sin(2 * x)))
+        rhs = s.computeRHS(*q, filter=True)
+        s.setState(*q)
+        s.stepRK2(2e-4, 3, filter=True)
+        return s.usesNodalTraces, 0 < curved.size < ctx.numElements, rhs, s.getState()
+
+    nt, mixed, rhs, state = run({})
+    assert nt and mixed
+    for env in ({"BDG_SW2D_CURVED_NO_TILE_ORDER": "1"}, {"BDG_SW2D_CURVED_PRIO": "0"}):
+        _, _, rhs2, state2 = run(env)
+        assert all(np.array_equal(a, b) for a, b in zip(rhs, rhs2)) and all(np.array_equal(a, b) for a, b in zip(state, state2)), env
+    nt3, _, rhs3, state3 = run({"BDG_SW2D_CURVED_GENERAL": "1"})
+    assert not nt3
+    assert relerr(rhs, rhs3) <= 5e-10 and relerr(state, state3) <= 5e-10
+    assert np.isfinite(state[0]).all()
+
+
 def test_bad_tables_are_refused_before_anything_runs():
     d = np.load(CURVED[0])
     ctx, cub, gauss = contexts_from_fixture(d)
