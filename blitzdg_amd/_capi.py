@@ -220,6 +220,7 @@ _SIGNATURES = {
     "bdg_sw2d_curved_set_partition": (c_int, [_P, c_int, c_int, _P, c_int]),
     "bdg_sw2d_curved_comm_init": (c_int, [_P, c_int, c_int, _P, _P, _P, _P, _P, _P, c_int]),
     "bdg_sw2d_curved_step_rk2_exchanged": (c_int, [_P, c_double, c_int, c_int]),
+    "bdg_sw2d_curved_lserk4_stages_exchanged": (c_int, [_P, c_double, c_int]),
     "bdg_sw2d_curved_exchange": (c_int, [_P, c_int]),
     "bdg_sw2d_curved_barrier": (c_int, [_P]),
 }

@@ -258,9 +258,39 @@ struct bdg_sw2d_curved {
     // for B(e-1); boundary(e) and its pack read / overwrite columns interior(e-1) wrote / read: B waits for A(e-1). Ghost
     // columns are written by the unpack and read by the boundary launch only, both on B. Ghost elements are not evaluated.
     // Otherwise (general form, or no interior elements): exchange, then every element, in stream order.
+    struct Chains { bool haveA = false, haveB = false; int e = 0; };
+    bool overlapped() const {
+        return useNT && numInterior >= 1 && std::getenv("BDG_SW2D_CURVED_NO_OVERLAP") == nullptr; // (A/B switch, read per call)
+    }
+    void chainsBegin(Chains&) {
+        hipOk(hipEventRecord(evEntry, stream), "hipEventRecord");          // whatever set the state, on A
+        hipOk(hipStreamWaitEvent(commStream, evEntry, 0), "hipStreamWaitEvent");
+    }
+    // one evaluation on both chains: reads `in` (ghost columns refreshed first), writes the owned columns of `out`
+    void chainsEval(Chains& c, int mode, bool filter, double* in, const double* base, double* out, double ca, double cb, double cc) {
+        // the interior launch is one resident round of workgroups that loop over their tiles: it leaves the slots the
+        // partition-boundary launch needs (a workgroup per four tiles, rounded up to the eight XCDs), or that launch would wait
+        const int boundaryWgs = (((numOwned - numInterior + 15) / 16 + 3) / 4 + 7) / 8 * 8;
+        const int cur = c.e & 1, prev = cur ^ 1;
+        // ---- chain A
+        if (c.haveB) hipOk(hipStreamWaitEvent(stream, evB[prev], 0), "hipStreamWaitEvent");
+        evaluateRange(mode, filter, in, base, out, ca, cb, cc, 0, numInterior, slotsInterior.p, numSlotsInterior, stream, boundaryWgs);
+        hipOk(hipEventRecord(evA[cur], stream), "hipEventRecord");
+        // ---- chain B
+        if (c.haveA) hipOk(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
+        exchangeOn(in, commStream);
+        evaluateRange(mode, filter, in, base, out, ca, cb, cc, numInterior, numOwned, slotsBoundary.p, numSlotsBoundary, commStream);
+        hipOk(hipEventRecord(evB[cur], commStream), "hipEventRecord");
+        c.haveA = c.haveB = true;
+        ++c.e;
+    }
+    void chainsEnd(Chains& c) { // join both ways: later work on A sees the last boundary update, later work on B the last interior launch
+        if (c.e == 0) return;
+        hipOk(hipStreamWaitEvent(stream, evB[(c.e - 1) & 1], 0), "hipStreamWaitEvent");
+        hipOk(hipStreamWaitEvent(commStream, evA[(c.e - 1) & 1], 0), "hipStreamWaitEvent");
+    }
     void stepRk2Exchanged(double dt, int steps, bool filter) {
-        const bool noOverlap = std::getenv("BDG_SW2D_CURVED_NO_OVERLAP") != nullptr; // (A/B switch, read per call)
-        if (!useNT || numInterior < 1 || noOverlap) {
+        if (!overlapped()) {
             for (int i = 0; i < steps; ++i) {
                 exchange(qA.p);
                 evaluate(bdg_dev::CMODE_COMBINE, filter, qA.p, qA.p, qB.p, 1.0, 0.0, 0.5 * dt);
@@ -269,35 +299,33 @@ struct bdg_sw2d_curved {
             }
             return;
         }
-        hipOk(hipEventRecord(evEntry, stream), "hipEventRecord");          // whatever set the state, on A
-        hipOk(hipStreamWaitEvent(commStream, evEntry, 0), "hipStreamWaitEvent");
-        bool haveA = false, haveB = false;
-        int e = 0;
-        // the interior launch is one resident round of workgroups that loop over their tiles: it leaves the slots the
-        // partition-boundary launch needs (a workgroup per four tiles, rounded up to the eight XCDs), or that launch would wait
-        const int boundaryWgs = (((numOwned - numInterior + 15) / 16 + 3) / 4 + 7) / 8 * 8;
-        for (int i = 0; i < steps; ++i)
-            for (int ph = 0; ph < 2; ++ph, ++e) {
-                double* in = ph == 0 ? qA.p : qB.p;
-                double* out = ph == 0 ? qB.p : qA.p;
-                const double cc = ph == 0 ? 0.5 * dt : dt;
-                const int cur = e & 1, prev = cur ^ 1;
-                // ---- chain A
-                if (haveB) hipOk(hipStreamWaitEvent(stream, evB[prev], 0), "hipStreamWaitEvent");
-                evaluateRange(bdg_dev::CMODE_COMBINE, filter, in, qA.p, out, 1.0, 0.0, cc, 0, numInterior, slotsInterior.p, numSlotsInterior, stream,
-                              boundaryWgs);
-                hipOk(hipEventRecord(evA[cur], stream), "hipEventRecord");
-                // ---- chain B
-                if (haveA) hipOk(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
-                exchangeOn(in, commStream);
-                evaluateRange(bdg_dev::CMODE_COMBINE, filter, in, qA.p, out, 1.0, 0.0, cc, numInterior, numOwned, slotsBoundary.p, numSlotsBoundary,
-                              commStream);
-                hipOk(hipEventRecord(evB[cur], commStream), "hipEventRecord");
-                haveA = haveB = true;
+        Chains c;
+        chainsBegin(c);
+        for (int i = 0; i < steps; ++i) {
+            chainsEval(c, bdg_dev::CMODE_COMBINE, filter, qA.p, qA.p, qB.p, 1.0, 0.0, 0.5 * dt);
+            chainsEval(c, bdg_dev::CMODE_COMBINE, filter, qB.p, qA.p, qA.p, 1.0, 0.0, dt);
+        }
+        chainsEnd(c);
+    }
+    // LSERK4 stages of a partitioned run (reference src/advec1d/main.cpp:92-102 per stage): res = a res + dt RHS(q); q += b res,
+    // an exchange of q in front of every stage; the nodal-trace form writes the other state buffer and the two swap roles
+    void lserkStagesExchanged(double dt, int numStages) {
+        Chains c;
+        const bool two = overlapped();
+        if (two) chainsBegin(c);
+        for (int i = 0; i < numStages; ++i) {
+            const int st = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
+            const double a = blitzdg::LSERK4::rk4a[st], b = blitzdg::LSERK4::rk4b[st];
+            if (two) {
+                chainsEval(c, bdg_dev::CMODE_LSERK, false, qA.p, nullptr, qB.p, a, b, dt);
+                std::swap(qA.p, qB.p);
+            } else {
+                exchange(qA.p);
+                lserkStage(a, b, dt);
             }
-        // join both ways: later work on A sees the last boundary update, later work on B the last interior launch
-        hipOk(hipStreamWaitEvent(stream, evB[(e - 1) & 1], 0), "hipStreamWaitEvent");
-        hipOk(hipStreamWaitEvent(commStream, evA[(e - 1) & 1], 0), "hipStreamWaitEvent");
+            ++stageCount;
+        }
+        if (two) chainsEnd(c);
     }
     void stepRk2(double dt, int steps, bool filter) {
         for (int i = 0; i < steps; ++i) {
@@ -1111,6 +1139,16 @@ int bdg_sw2d_curved_step_rk2_exchanged(bdg_sw2d_curved* s, double dt, int num_st
         if (num_steps < 0) throw arg_error("bdg_sw2d_curved_step_rk2_exchanged: num_steps < 0");
         s->use();
         s->stepRk2Exchanged(dt, num_steps, filter != 0);
+    });
+}
+
+int bdg_sw2d_curved_lserk4_stages_exchanged(bdg_sw2d_curved* s, double dt, int num_stages) {
+    return guard([&] {
+        requireCurved(s, "bdg_sw2d_curved_lserk4_stages_exchanged");
+        if (num_stages < 0) throw arg_error("bdg_sw2d_curved_lserk4_stages_exchanged: num_stages < 0");
+        if (!s->comm) throw arg_error("bdg_sw2d_curved_lserk4_stages_exchanged: no communicator (call bdg_sw2d_curved_comm_init first)");
+        s->use();
+        s->lserkStagesExchanged(dt, num_stages);
     });
 }
 

@@ -214,6 +214,12 @@ class DistributedSw2dCurved:
             self._exchange(True)
             self.solver.rk2Phase(dt, 1, self.filtered)
 
+    def lserk4_stages(self, dt, nstages):
+        """Sw2dCurvedSolver.lserk4Stages with an exchange in front of every stage."""
+        for _ in range(nstages):
+            self._exchange(False)
+            self.solver.lserk4Stages(dt, 1)
+
     def owned_state(self):
         n = self.plan.num_owned
         return (self.plan.own_global,) + tuple(a[:, :n] for a in self.solver.getState())
@@ -279,6 +285,10 @@ class NativeDistributedSw2dCurved(DistributedSw2dCurved):
 
     def step_rk2(self, dt, nsteps=1):
         check(lib.bdg_sw2d_curved_step_rk2_exchanged(self.solver._h, float(dt), int(nsteps), int(self.filtered)))
+
+    def lserk4_stages(self, dt, nstages):
+        """Sw2dCurvedSolver.lserk4Stages with an exchange in front of every stage."""
+        check(lib.bdg_sw2d_curved_lserk4_stages_exchanged(self.solver._h, float(dt), int(nstages)))
 
     def barrier(self):
         check(lib.bdg_sw2d_curved_barrier(self.solver._h))

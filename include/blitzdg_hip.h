@@ -481,6 +481,7 @@ int bdg_sw2d_curved_comm_init(bdg_sw2d_curved* s, int rank, int world, const voi
                               const int* send_start, const int* send_count, const int* recv_start, const int* recv_count,
                               int num_peers);
 int bdg_sw2d_curved_step_rk2_exchanged(bdg_sw2d_curved* s, double dt, int num_steps, int filter);
+int bdg_sw2d_curved_lserk4_stages_exchanged(bdg_sw2d_curved* s, double dt, int num_stages); /* bdg_sw2d_curved_lserk4_stages, an exchange in front of every stage */
 int bdg_sw2d_curved_exchange(bdg_sw2d_curved* s, int which);
 int bdg_sw2d_curved_barrier(bdg_sw2d_curved* s);
 size_t bdg_sw2d_curved_device_bytes(const bdg_sw2d_curved* s);

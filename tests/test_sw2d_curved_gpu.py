@@ -261,7 +261,7 @@ def _dist_sources(x, y):
     return {"zx": 0.05 + 0 * x, "zy": -0.04 * y, "f": 0.0788, "CD": 2.5e-3 * (1.0 + 0.5 * np.cos(x))}
 
 
-def _curved_rank_worker(rank, world, port, out_dir, general, native_env=None):
+def _curved_rank_worker(rank, world, port, out_dir, general, native_env=None, stepper="rk2"):
     import sys
     from blitzdg_amd.halo import build_plan
     from blitzdg_amd.sw2d_curved import DistributedSw2dCurved, NativeDistributedSw2dCurved
@@ -285,8 +285,12 @@ def _curved_rank_worker(rank, world, port, out_dir, general, native_env=None):
         d = DistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, dist, **kw)
     try:
         d.set_initial_state(_dist_state)
-        d.step_rk2(DIST_DT, 1)                # several calls
-        d.step_rk2(DIST_DT, DIST_STEPS - 1)
+        if stepper == "rk2":
+            d.step_rk2(DIST_DT, 1)                # several calls
+            d.step_rk2(DIST_DT, DIST_STEPS - 1)
+        else:
+            d.lserk4_stages(DIST_DT, 3)
+            d.lserk4_stages(DIST_DT, 5 * DIST_STEPS - 3)
         out = d.owned_state()
         if native_env is not None:
             d.barrier()
@@ -297,20 +301,22 @@ def _curved_rank_worker(rank, world, port, out_dir, general, native_env=None):
     sys.stdout.flush()
 
 
-@pytest.mark.parametrize("world,transport", [(2, "gloo"), (3, "gloo"), (2, "native"), (3, "native")])
-def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world, transport, form, mock_rccl):
+@pytest.mark.parametrize("world,transport,stepper", [(2, "gloo", "rk2"), (3, "gloo", "rk2"), (2, "native", "rk2"), (3, "native", "rk2"),
+                                                     (2, "gloo", "lserk4"), (3, "native", "lserk4")])
+def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world, transport, stepper, form, mock_rccl):
     """DistributedSw2dCurved / NativeDistributedSw2dCurved: each rank owns a part of a deformed, shuffled box mesh plus a ghost
     layer, refreshes the ghost columns before every RHS evaluation -- host-staged over gloo, or by the library itself
     (bdg_sw2d_curved_comm_init / _step_rk2_exchanged: pack kernel, grouped send / receive, unpack kernel, with only librccl.so
-    replaced by tests/mock_rccl) -- and runs the driver's RK2 + filter steps; the owned states equal the single-domain solver's to
-    round-off (the tiling of the elements differs between the runs, so not bit for bit)."""
+    replaced by tests/mock_rccl) -- and runs the driver's RK2 + filter steps, or LSERK4 stages with an exchange in front of each;
+    the owned states equal the single-domain solver's to round-off (the tiling of the elements differs between the runs, so not
+    bit for bit)."""
     import socket
     from conftest import launch_ranks
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     launch_ranks("test_sw2d_curved_gpu", "_curved_rank_worker", world,
-                 (world, port, str(tmp_path), form == "general", mock_rccl if transport == "native" else None))
+                 (world, port, str(tmp_path), form == "general", mock_rccl if transport == "native" else None, stepper))
     mesh = dg.MeshManager()
     mesh.buildBoxMesh(*DIST_MESH, shuffleSeed=5)
     nodes = dg.TriangleNodesProvisioner(DIST_ORDER, mesh)
@@ -325,7 +331,10 @@ def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world
     s = Sw2dCurvedSolver(ctx, cub, gauss, curved, J, gauss.mapM, gauss.mapP, g=0.0245, zx=src["zx"], zy=src["zy"], f=src["f"], CD=src["CD"])
     q0 = _dist_state(x, y)
     s.setState(*q0)
-    s.stepRK2(DIST_DT, DIST_STEPS, filter=True)
+    if stepper == "rk2":
+        s.stepRK2(DIST_DT, DIST_STEPS, filter=True)
+    else:
+        s.lserk4Stages(DIST_DT, 5 * DIST_STEPS)
     ref = s.getState()
     seen = np.zeros(mesh.numElements, dtype=int)
     for r in range(world):
