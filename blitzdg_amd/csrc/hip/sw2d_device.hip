@@ -510,9 +510,14 @@ struct bdg_sw2d {
 
     // part: 0 = interior elements only (no ghost dependency; state not advanced),
     //       1 = partition-boundary elements, then advance; 2 = all owned elements, then advance.
-    void launchLserkStage(int part = 2, hipStream_t on = nullptr, bool advance = true) {
+    // done: an event to record when this launch has finished -- through the launch itself where its helper can (one packet
+    // on the queue instead of two), by a record behind it otherwise
+    void launchLserkStage(int part = 2, hipStream_t on = nullptr, bool advance = true, hipEvent_t done = nullptr) {
         const int s = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
         bdg_dev::StageParams p = baseParams();
+        bool recorded = false;
+        static const bool extLaunch = [] { const char* e = std::getenv("BDG_SW2D_EXT_LAUNCH"); return !e || e[0] != '0'; }();
+        if (done && extLaunch) { p.stopEvent = done; p.stopEventUsed = &recorded; }
         if (part == 0) {
             p.kend = numInterior;
             p.gridCap = interiorGridCap(); // the boundary kernel runs beside this launch (exchange stream)
@@ -528,6 +533,7 @@ struct bdg_sw2d {
         const bool lastOfStep = s == blitzdg::LSERK4::numStages - 1;
         nextEvalTime = lastOfStep ? timeNow + dtStage : timeNow;
         launchStage(bdg_dev::MODE_LSERK, false, p, "sw2d stage kernel <LSERK>", on);
+        if (done && !recorded) hipCheck(hipEventRecord(done, on ? on : stream), "hipEventRecord");
         if (part == 0 || !advance) return;
         std::swap(qcur, qalt);
         ++stageCount;
@@ -611,9 +617,12 @@ struct bdg_sw2d {
         return N >= 5 || numOwned - numInterior < kSmallLaunch[N]; // the strip runs on a matrix-core kernel
     }
     // LSERK4 stage of the partition-boundary elements: reads ghost traces from recv, writes send records
-    void launchBoundaryStageFolded(hipStream_t on, const double* recv, double* send) {
+    void launchBoundaryStageFolded(hipStream_t on, const double* recv, double* send, hipEvent_t done = nullptr) {
         const int st = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
         bdg_dev::StageParams p = baseParams();
+        bool recorded = false;
+        static const bool extLaunch = [] { const char* e = std::getenv("BDG_SW2D_EXT_LAUNCH"); return !e || e[0] != '0'; }();
+        if (done && extLaunch) { p.stopEvent = done; p.stopEventUsed = &recorded; }
         p.kbegin = numInterior;
         p.qin = qcur; p.qout = qalt; p.res = res.p;
         p.ca = blitzdg::LSERK4::rk4a[st]; p.cb = blitzdg::LSERK4::rk4b[st]; p.cc = dtStage;
@@ -628,6 +637,7 @@ struct bdg_sw2d {
             p.opsAffine = opsMfma.p;
             hipCheck(kt->stageMfmaHalo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
         }
+        if (done && !recorded) hipCheck(hipEventRecord(done, on), "hipEventRecord");
         std::swap(qcur, qalt);
         ++stageCount;
         if (st == blitzdg::LSERK4::numStages - 1) timeNow += dtStage;
@@ -665,8 +675,7 @@ struct bdg_sw2d {
             const int cur = i & 1, prev = cur ^ 1;
             // ---- chain A
             if (haveB) hipCheck(hipStreamWaitEvent(stream, evB[prev], 0), "hipStreamWaitEvent");
-            launchLserkStage(0);
-            hipCheck(hipEventRecord(evA[cur], stream), "hipEventRecord");
+            launchLserkStage(0, nullptr, true, evA[cur]);
             // ---- chain B
             if (!fold) launchPack(sendBuf.p, commStream);
             if (!peers.empty()) {
@@ -686,9 +695,8 @@ struct bdg_sw2d {
             }
             if (!fold) launchUnpack(recvBuf.p, commStream);
             if (haveA) hipCheck(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
-            if (fold) launchBoundaryStageFolded(commStream, recvBuf.p, sendBuf.p);
-            else launchLserkStage(1, commStream);              // partition-boundary elements, advance
-            hipCheck(hipEventRecord(evB[cur], commStream), "hipEventRecord");
+            if (fold) launchBoundaryStageFolded(commStream, recvBuf.p, sendBuf.p, evB[cur]);
+            else launchLserkStage(1, commStream, true, evB[cur]); // partition-boundary elements, advance
             haveA = haveB = true;
         }
         // later work on A (dt reduction, downloads, plain stages) sees the last boundary update

@@ -90,6 +90,11 @@ struct StageParams {
     int stagger;
     // profiling builds (-DBDG_PHASE_CLOCK): 16 cycle counts per wave (LDS copy, k-steps, surface, update), else unused
     unsigned long long* phaseClock;
+    // host side only (the launch helpers of sw2d_order.hip): when set, the launch records this event through its own completion
+    // signal (hipExtLaunchKernelGGL) instead of a separate record packet behind it, and sets *stopEventUsed; a launch path that
+    // does not look at it leaves the flag alone and the caller records the event itself
+    hipEvent_t stopEvent;
+    bool* stopEventUsed;
 };
 
 // Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):

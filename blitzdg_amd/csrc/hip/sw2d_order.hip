@@ -1,5 +1,6 @@
 // Instantiates the sw2d kernels for one polynomial order (-DBDG_ORDER=N).
 #include "sw2d_launch.hpp"
+#include <hip/hip_ext.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,18 @@
 #ifndef BDG_ORDER
 #error "compile with -DBDG_ORDER=<polynomial order>"
 #endif
+
+// A launch that records p.stopEvent (when set) through the dispatch's own completion signal: one packet instead of two on the
+// queue, which is what the dependent launch on the other stream of a partitioned stage waits behind (sw2d_device.hip).
+#define BDG_LAUNCH_EV(kern, grid, block, lds, stream, p, ...)                                                          \
+    do {                                                                                                                \
+        if ((p).stopEvent) {                                                                                            \
+            hipExtLaunchKernelGGL(kern, grid, block, lds, stream, nullptr, (p).stopEvent, 0, p, ##__VA_ARGS__);         \
+            if ((p).stopEventUsed) *(p).stopEventUsed = true;                                                           \
+        } else {                                                                                                        \
+            hipLaunchKernelGGL(kern, grid, block, lds, stream, p, ##__VA_ARGS__);                                       \
+        }                                                                                                               \
+    } while (0)
 
 namespace bdg_dev {
 namespace {
@@ -90,7 +103,7 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
             return hipGetLastError();
         }
     }
-    hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
+    BDG_LAUNCH_EV((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
     return hipGetLastError();
     }
 }
@@ -216,7 +229,7 @@ hipError_t stageMfmaHalo(const StageParams& p, hipStream_t stream) {
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(8, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
-    hipLaunchKernelGGL((sw2d_stage_mfma_kernel<kN, MODE_LSERK, true>), dim3(grid), dim3(256), ldsBytes, stream, p);
+    BDG_LAUNCH_EV((sw2d_stage_mfma_kernel<kN, MODE_LSERK, true>), dim3(grid), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }
 
@@ -293,7 +306,7 @@ hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
     return hipGetLastError();
 #else
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
+    BDG_LAUNCH_EV(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
     return hipGetLastError();
 #endif
 }
@@ -324,10 +337,10 @@ hipError_t stageMfma3Halo(const StageParams& p, hipStream_t stream) {
     // boundary sets: the throughput form.
     if (ntiles <= 1024u && !std::getenv("BDG_SW2D_STRIP_THROUGHPUT")) {
         const size_t stripLds = sizeof(double) * MfmaOps2<kN>::DOUBLES;
-        hipLaunchKernelGGL((sw2d_strip_mfma3_kernel<kN>), dim3(ntiles), dim3(192), stripLds, stream, p);
+        BDG_LAUNCH_EV((sw2d_strip_mfma3_kernel<kN>), dim3(ntiles), dim3(192), stripLds, stream, p);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(kern, dim3(std::min((ntiles + 3u) / 4u, 256u)), dim3(256), ldsBytes, stream, p);
+    BDG_LAUNCH_EV(kern, dim3(std::min((ntiles + 3u) / 4u, 256u)), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }
 
