@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 
 namespace bdg_rccl {
@@ -23,32 +24,45 @@ struct RcclApi {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+// The table is published only once all nine entry points are bound: a library that lacks one (a BDG_RCCL_LIBRARY without,
+// say, ncclAllReduce) makes EVERY call throw, instead of the first one throwing and the later ones jumping through a
+// half-filled table. First calls from two threads are serialised by the mutex.
 inline RcclApi& rccl() {
     static RcclApi api;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> hold(lock);
     if (api.handle) return api;
+    RcclApi local;
     // BDG_RCCL_LIBRARY: another library with the same nine entry points (the tests substitute a file-based
     // transport so that several ranks can share the one GPU of a test box, which RCCL itself refuses).
     const char* names[] = {std::getenv("BDG_RCCL_LIBRARY"), "librccl.so.1", "librccl.so"};
     for (const char* n : names) {
         if (!n || !*n) continue;
-        api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (api.handle) break;
+        local.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (local.handle) break;
     }
-    if (!api.handle) throw bdg_detail::hip_error(std::string("cannot load RCCL: ") + dlerror());
+    if (!local.handle) {
+        const char* why = dlerror();
+        throw bdg_detail::hip_error(std::string("cannot load RCCL: ") + (why ? why : "no library name given"));
+    }
     auto sym = [&](const char* name) {
-        void* p = dlsym(api.handle, name);
-        if (!p) throw bdg_detail::hip_error(std::string("RCCL symbol missing: ") + name);
+        void* p = dlsym(local.handle, name);
+        if (!p) {
+            dlclose(local.handle);
+            throw bdg_detail::hip_error(std::string("RCCL symbol missing: ") + name);
+        }
         return p;
     };
-    api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
-    api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
-    api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
-    api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
-    api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
-    api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
-    api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
-    api.AllReduce = reinterpret_cast<decltype(api.AllReduce)>(sym("ncclAllReduce"));
-    api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+    local.GetUniqueId = reinterpret_cast<decltype(local.GetUniqueId)>(sym("ncclGetUniqueId"));
+    local.CommInitRank = reinterpret_cast<decltype(local.CommInitRank)>(sym("ncclCommInitRank"));
+    local.CommDestroy = reinterpret_cast<decltype(local.CommDestroy)>(sym("ncclCommDestroy"));
+    local.GroupStart = reinterpret_cast<decltype(local.GroupStart)>(sym("ncclGroupStart"));
+    local.GroupEnd = reinterpret_cast<decltype(local.GroupEnd)>(sym("ncclGroupEnd"));
+    local.Send = reinterpret_cast<decltype(local.Send)>(sym("ncclSend"));
+    local.Recv = reinterpret_cast<decltype(local.Recv)>(sym("ncclRecv"));
+    local.AllReduce = reinterpret_cast<decltype(local.AllReduce)>(sym("ncclAllReduce"));
+    local.GetErrorString = reinterpret_cast<decltype(local.GetErrorString)>(sym("ncclGetErrorString"));
+    api = local;
     return api;
 }
 

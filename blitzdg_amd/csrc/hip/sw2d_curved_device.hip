@@ -55,6 +55,7 @@ struct Buf {
     T* p = nullptr;
     size_t n = 0;
     void alloc(size_t count, size_t& total, hipStream_t stream) {
+        if (p) total -= std::min(total, n * sizeof(T)); // a replaced buffer no longer counts (repeated set_partition)
         release();
         if (count == 0) return;
         hipOk(hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)), "hipMalloc");
@@ -122,6 +123,7 @@ struct bdg_sw2d_curved {
     // stream while the exchange and then the partition-boundary elements [numInterior, numOwned) run on commStream; the curved
     // elements of the two ranges (columns of the side buffer) are listed for the fix-up launches of either chain
     std::vector<int> curvedHost;          // element of each side-buffer column
+    std::vector<int> maxNeighbourHost;    // largest element index a face of element k is paired with (from gmapP, kept for set_partition)
     Buf<int> slotsInterior, slotsBoundary;
     int numSlotsInterior = 0, numSlotsBoundary = 0;
     hipStream_t commStream = nullptr;
@@ -655,6 +657,13 @@ bdg_sw2d_curved* createCurved(const bdg_sw2d_curved_desc& d) {
             if (!identityM) offM[at] = devOffset(d.gmapM[static_cast<size_t>(k) * NG3 + gI]);
         }
     });
+    std::vector<int> maxNeighbour(static_cast<size_t>(K), 0);
+    blitzdg::detail::parallelFor(K, [&](int k) {
+        int m = k;
+        for (int gI = 0; gI < NG3; ++gI) m = std::max(m, d.gmapP[static_cast<size_t>(k) * NG3 + gI] / NG3);
+        maxNeighbour[static_cast<size_t>(k)] = m;
+    });
+    s->maxNeighbourHost = std::move(maxNeighbour);
     for (int i = 0; i < d.num_wall; ++i) {
         const int w = d.gmapW[i];
         if (w < 0 || w >= nG) throw arg_error("bdg_sw2d_curved_create: wall Gauss-node index out of range");
@@ -1067,6 +1076,17 @@ int bdg_sw2d_curved_set_partition(bdg_sw2d_curved* s, int num_interior, int num_
         for (int i = 0; i < num_send; ++i)
             if (send_elements[i] < 0 || send_elements[i] >= num_owned)
                 throw arg_error("bdg_sw2d_curved_set_partition: a send element is not an owned element");
+        // The two-chain schedule evaluates [0, num_interior) beside the exchange: it is race-free only if no such element
+        // reads a ghost column and none of them is packed for a neighbour. A plan that breaks either is refused here
+        // (it would otherwise give stale ghost reads, not an error).
+        for (int k = 0; k < num_interior; ++k)
+            if (s->maxNeighbourHost[static_cast<size_t>(k)] >= num_owned)
+                throw arg_error("bdg_sw2d_curved_set_partition: element " + std::to_string(k) +
+                                " is listed as interior but has a ghost neighbour (elements >= num_owned)");
+        for (int i = 0; i < num_send; ++i)
+            if (send_elements[i] < num_interior)
+                throw arg_error("bdg_sw2d_curved_set_partition: send element " + std::to_string(send_elements[i]) +
+                                " lies in the interior range [0, num_interior)");
         if (s->comm) throw arg_error("bdg_sw2d_curved_set_partition: the communicator is already initialised");
         s->use();
         s->numOwned = num_owned;
@@ -1137,6 +1157,7 @@ int bdg_sw2d_curved_step_rk2_exchanged(bdg_sw2d_curved* s, double dt, int num_st
     return guard([&] {
         requireCurved(s, "bdg_sw2d_curved_step_rk2_exchanged");
         if (num_steps < 0) throw arg_error("bdg_sw2d_curved_step_rk2_exchanged: num_steps < 0");
+        if (!s->comm) throw arg_error("bdg_sw2d_curved_step_rk2_exchanged: no communicator (call bdg_sw2d_curved_comm_init first)");
         s->use();
         s->stepRk2Exchanged(dt, num_steps, filter != 0);
     });

@@ -182,6 +182,7 @@ class DistributedSw2dCurved:
                                        f=src.get("f", 0.0), CD=src.get("CD", 0.0), device=device)
         self.nodes, self.ctx, self.cub, self.x, self.y = nodes, ctx, cub, x, y
         self.filtered = filter_args is not None
+        self.device = device                      # the exchange buffers of the nccl backend live on the solver's GPU
         self._on_device = dist.get_backend() == "nccl"
 
     def set_initial_state(self, fn):
@@ -195,7 +196,7 @@ class DistributedSw2dCurved:
         rows = 4 * self.solver.Np
         boundary = self.solver.getElements(n_int, n_own - n_int, intermediate)          # the partition-boundary block
         send = np.ascontiguousarray(boundary[:, plan.send_local - n_int].T)               # (n_send, rows): one record per element
-        dev = torch.device("cuda", 0) if self._on_device else torch.device("cpu")
+        dev = torch.device("cuda", self.device) if self._on_device else torch.device("cpu")
         sendbuf = torch.from_numpy(send).to(dev)
         recvbuf = torch.zeros((max(plan.num_halo, 1), rows), dtype=torch.float64, device=dev)
         from .halo import exchange_ops

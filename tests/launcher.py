@@ -14,19 +14,45 @@ The commands of one request run side by side; when one of them fails the others 
 then killed (the way torch.multiprocessing.start_processes(join=True) treats its workers).
 """
 import json
+import os
+import signal
 import subprocess
 import sys
 import tempfile
 import time
 
 
+def _kill_group(p):
+    """Ends the process group child `p` leads (start_new_session=True below): the child AND whatever it started in turn --
+    the ranks under torch.distributed.run, hipcc's subprocesses -- which would otherwise keep the GPU. Exactly the group
+    created here, nothing found by pattern."""
+    try:
+        os.killpg(p.pid, signal.SIGKILL)
+    except (ProcessLookupError, PermissionError):
+        pass
+    if p.poll() is None:
+        p.kill()
+
+
 def run_group(cmds, timeout, grace=20.0):
     procs, files = [], []
-    for c in cmds:
-        out, err = tempfile.TemporaryFile(), tempfile.TemporaryFile()   # files, not pipes: no reader threads needed
-        files.append((out, err))
-        procs.append(subprocess.Popen(c["argv"], env=c.get("env"), cwd=c.get("cwd"), stdin=subprocess.DEVNULL,
-                                      stdout=out, stderr=err))
+    try:
+        for c in cmds:
+            out, err = tempfile.TemporaryFile(), tempfile.TemporaryFile()   # files, not pipes: no reader threads needed
+            files.append((out, err))
+            procs.append(subprocess.Popen(c["argv"], env=c.get("env"), cwd=c.get("cwd"), stdin=subprocess.DEVNULL,
+                                          stdout=out, stderr=err, start_new_session=True))
+    except Exception:
+        # a later command could not be started (missing executable): the ranks already running would sit in their
+        # rendezvous holding the GPU -- end them, reap them, drop their files, then report the error
+        for p in procs:
+            _kill_group(p)
+        for p in procs:
+            p.wait()
+        for out, err in files:
+            out.close()
+            err.close()
+        raise
     deadline = time.monotonic() + timeout
     failed_at = None
     while any(p.poll() is None for p in procs):
@@ -36,12 +62,14 @@ def run_group(cmds, timeout, grace=20.0):
         if now > deadline or (failed_at is not None and now > failed_at + grace):
             for p in procs:
                 if p.poll() is None:
-                    p.kill()        # the exact processes started above, nothing found by pattern
+                    _kill_group(p)
             break
         time.sleep(0.02)
     results = []
     for p, (out, err) in zip(procs, files):
         p.wait()
+        if p.returncode != 0:
+            _kill_group(p)          # a failed or killed child may have left grandchildren in its group
         texts = []
         for f in (out, err):
             f.seek(0)

@@ -280,9 +280,16 @@ def _curved_rank_worker(rank, world, port, out_dir, general, native_env=None, st
         d = NativeDistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, **kw)
         assert "torch" not in sys.modules
     else:
+        import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-        d = DistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, dist, **kw)
+        backend = "nccl" if world == 1 else "gloo"   # one rank: the RCCL backend's device-side staging (buffers on the solver's GPU)
+        if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            torch.cuda.set_device(0)
+        pg = {"device_id": torch.device("cuda", 0)} if backend == "nccl" else {}
+        dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, **pg)
+        d = DistributedSw2dCurved(plan, DIST_ORDER, _dist_deform, dist, device=0, **kw)
+        assert d._on_device == (backend == "nccl") and d.device == 0
     try:
         d.set_initial_state(_dist_state)
         if stepper == "rk2":
@@ -302,7 +309,7 @@ def _curved_rank_worker(rank, world, port, out_dir, general, native_env=None, st
 
 
 @pytest.mark.parametrize("world,transport,stepper", [(2, "gloo", "rk2"), (3, "gloo", "rk2"), (2, "native", "rk2"), (3, "native", "rk2"),
-                                                     (2, "gloo", "lserk4"), (3, "native", "lserk4")])
+                                                     (2, "gloo", "lserk4"), (3, "native", "lserk4"), (1, "nccl", "rk2")])
 def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world, transport, stepper, form, mock_rccl):
     """DistributedSw2dCurved / NativeDistributedSw2dCurved: each rank owns a part of a deformed, shuffled box mesh plus a ghost
     layer, refreshes the ghost columns before every RHS evaluation -- host-staged over gloo, or by the library itself
@@ -340,7 +347,7 @@ def test_partitioned_curved_solver_matches_the_single_domain_run(tmp_path, world
     for r in range(world):
         p = np.load(tmp_path / f"curved{r}.npz")
         seen[p["ids"]] += 1
-        assert int(p["ghosts"]) > 0
+        assert int(p["ghosts"]) > 0 or world == 1
         for i, full in enumerate(ref):
             assert np.abs(p[f"q{i}"] - full[:, p["ids"]]).max() <= STATE_TOL * np.abs(full).max(), f"field {i} differs on rank {r}"
     assert (seen == 1).all() and 0 < curved.size < mesh.numElements
@@ -463,3 +470,30 @@ def test_bad_tables_are_refused_before_anything_runs():
         Sw2dCurvedSolver(ctx, cub, gauss, [d["J"].shape[1]], d["J"], d["gmapM"], d["gmapP"], g=1.0)
     with pytest.raises(BdgError, match="positive"):
         Sw2dCurvedSolver(ctx, cub, gauss, d["curvedEls"], -d["J"], d["gmapM"], d["gmapP"], g=1.0)
+
+
+def test_set_partition_refuses_a_plan_that_would_race(form):
+    """bdg_sw2d_curved_set_partition: the two-chain schedule evaluates [0, num_interior) beside the ghost exchange, so an
+    'interior' element with a ghost neighbour or one that is packed for a neighbour is an argument error, not a silent race;
+    and the exchanged steppers refuse to run without a communicator."""
+    from ctypes import POINTER, c_int
+    from blitzdg_amd._capi import check, lib
+    d = np.load(os.path.join(GOLDEN, "sw2d_rhs_curved_coarse_box_N3.npz"))
+    s = solver_from_fixture(d)
+    K = d["J"].shape[1]
+    gm = d["gmapP"].reshape(K, -1) // (d["gmapP"].size // K)      # neighbour element of every Gauss point
+    inner = int(np.flatnonzero(gm.max(axis=1) >= K - 5).min())    # first element with a neighbour among the last five
+    none = np.zeros(1, dtype=np.int32)
+    ptr = lambda a: a.ctypes.data_as(POINTER(c_int))              # noqa: E731
+    with pytest.raises(BdgError, match="ghost neighbour"):
+        check(lib.bdg_sw2d_curved_set_partition(s._h, inner + 1, K - 5, ptr(none), 0))
+    send = np.array([inner], dtype=np.int32)
+    with pytest.raises(BdgError, match="interior range"):
+        check(lib.bdg_sw2d_curved_set_partition(s._h, inner + 1, K, ptr(send), 1))
+    assert 0 < inner < K - 5
+    check(lib.bdg_sw2d_curved_set_partition(s._h, inner, K - 5, ptr(none), 0))   # a consistent plan
+    held = s.deviceBytes
+    check(lib.bdg_sw2d_curved_set_partition(s._h, inner, K - 5, ptr(none), 0))
+    assert s.deviceBytes == held                                   # a replaced buffer is not counted twice
+    with pytest.raises(BdgError, match="no communicator"):
+        check(lib.bdg_sw2d_curved_step_rk2_exchanged(s._h, 1e-3, 1, 0))
