@@ -95,6 +95,7 @@ _P = c_void_p
 _SIGNATURES = {
     "bdg_last_error": (c_char_p, []),
     "bdg_version": (c_int, []),
+    "bdg_vandermonde1d": (c_int, [_P, c_int, c_int, _P, _P]),
     "bdg_mesh_create": (c_int, [POINTER(_P)]),
     "bdg_mesh_destroy": (None, [_P]),
     "bdg_mesh_read": (c_int, [_P, c_char_p]),

@@ -542,6 +542,20 @@ int bdg_lserk4_num_stages(void) { return LSERK4::numStages; }
 const double* bdg_lserk4_a(void) { return LSERK4::rk4a; }
 const double* bdg_lserk4_b(void) { return LSERK4::rk4b; }
 
+int bdg_vandermonde1d(const double* r, int num_points, int num_cols, double* V, double* Vinv) {
+    return guard([&] {
+        if (!r || !V || num_points < 1 || num_cols < 1) throw bdg_detail::arg_error("bdg_vandermonde1d: bad argument");
+        if (Vinv && num_points != num_cols)
+            throw bdg_detail::arg_error("bdg_vandermonde1d: the inverse needs a square matrix (num_points == num_cols)");
+        real_vector_type rv(num_points);
+        std::copy(r, r + num_points, rv.data());
+        real_matrix_type Vm(num_points, num_cols), Vi(num_cols, num_cols);
+        blitzdg::VandermondeBuilders().computeVandermondeMatrix(rv, Vm, Vi, Vinv != nullptr);
+        std::copy(Vm.data(), Vm.data() + static_cast<size_t>(num_points) * num_cols, V);
+        if (Vinv) std::copy(Vi.data(), Vi.data() + static_cast<size_t>(num_cols) * num_cols, Vinv);
+    });
+}
+
 int bdg_nodes1d_advec_rhs(bdg_nodes1d* nodes, const double* u, double c, double* rhs) {
     return guard([&] {
         if (!nodes || !u || !rhs) throw bdg_detail::arg_error("bdg_nodes1d_advec_rhs: NULL argument");

@@ -40,6 +40,21 @@ class _LSERK4:
 LSERK4 = _LSERK4()
 
 
+class VandermondeBuilder:
+    """reference: src/pyblitzdg/pyblitzdg.cpp:92-93 (VandermondeBuilders::buildVandermondeMatrix_numpy,
+    include/VandermondeBuilders.hpp:76-105). V[i, j] = P_j^(0,0)(r[i]), orthonormal Legendre polynomials; a tuple
+    (V, Vinv) with includeInverse, else the 1-tuple (V,) -- the reference's own return shapes."""
+
+    def buildVandermondeMatrix(self, r, includeInverse=True, order=-1):
+        r = np.ascontiguousarray(r, dtype=np.float64).reshape(-1)
+        m = r.size
+        n = order + 1 if order > -1 else m
+        V = np.zeros((m, n))
+        Vinv = np.zeros((n, n)) if includeInverse else None
+        check(lib.bdg_vandermonde1d(C.ptr(r), m, n, C.ptr(V), C.ptr(Vinv) if includeInverse else None))
+        return (V, Vinv) if includeInverse else (V,)
+
+
 class TriangleCubatureRules:
     """reference: include/TriangleCubatureRules.hpp:11-1830 (a C++-only class there): the tabulated symmetric rule of
     degree NCubature = 1..28 on the reference triangle; a computed conical-product rule beyond the table."""

@@ -182,6 +182,13 @@ int bdg_lserk4_num_stages(void);
 const double* bdg_lserk4_a(void);
 const double* bdg_lserk4_b(void);
 
+/* VandermondeBuilders::buildVandermondeMatrix_numpy (reference include/VandermondeBuilders.hpp:76-105, Python name
+ * VandermondeBuilder.buildVandermondeMatrix, src/pyblitzdg/pyblitzdg.cpp:92-93): V(i, j) = P_j^(0,0)(r_i), the orthonormal
+ * Legendre polynomials at the num_points entries of r, j = 0 .. num_cols - 1 (the reference: num_cols = order + 1, or
+ * num_points when order < 0). V is (num_points, num_cols) row-major; with Vinv != NULL (needs num_points == num_cols)
+ * the inverse is written there too. Host only. */
+int bdg_vandermonde1d(const double* r, int num_points, int num_cols, double* V, double* Vinv);
+
 /* advec1d: CPU plumbing config (reference src/advec1d/main.cpp:35-122). Runs the
  * LSERK4 loop on the host to t >= final_time and returns the max-norm error
  * against the translated Gaussian. No GPU involved. */

@@ -35,6 +35,8 @@ Writes
                             the same function over a continuous, non-flat bed (zx = -Hx, zy = -Hy) on a state with
                             v = 0 and |u| + sqrt(g h) uniform, without and with drag: variant B's star states,
                             bed-slope source and RHS2 drag must reproduce it
+  curved_helpers_<case>.npz the reference's correctBCTable / makeMapsPeriodic (swhelpers/maps.py:3-65) and adjustStraightEdges /
+                            deformAndBlendElements (meshhelpers/curved.py:5-136) on a channel with a headland, inputs and outputs
   advec1d_rhs_N4_K100.npz   advec1dComputeRHS(u, c, nodes1d) of the reference SCRIPT advec1d.py:12-39
   sw2d_rhsC_<case>.npz      sw2dComputeRHS(h,hu,hv,hN,g,H,f,ctx) of the reference SCRIPT sw2d.py:37-146
                             ("variant C"), its two function definitions compiled on their own
@@ -362,6 +364,90 @@ def script_functions(path, names):
     return scope
 
 
+def curved_helpers_case(name="channel32x6_N4", order=4, nx=32, ny=6, seed=7):
+    """The set-up helpers of the reference's curved driver on a channel of the driver's size ([0, 8000] x [0, 1000], open
+    ends at x = 0 and x = 8000, a headland bump in the top wall), in the order sw2d_curved.py:43-145 calls them; every output
+    is that of the REFERENCE function:
+      correctBCTable, makeMapsPeriodic            imported from /root/reference/swhelpers/maps.py
+      adjustStraightEdges, deformAndBlendElements the two function definitions of /root/reference/meshhelpers/curved.py compiled
+                                                  on their own (the module imports the compiled pyblitzdg, which does not exist
+                                                  here) with numpy, scipy's splev and -- for its one call into pyblitzdg,
+                                                  VandermondeBuilder().buildVandermondeMatrix -- this repository's mirror of that
+                                                  class in scope (1-D orthonormal Legendre Vandermonde matrix, pinned against the
+                                                  reference's literals by tests/test_setup_golden.py)
+    The context handed to the two curved helpers HOLDS its x / y arrays (a SimpleNamespace), so the blending they do in place is
+    what they return (with the reference's own DGContext2D every access of ctx.x is a fresh copy and the blending is lost)."""
+    import blitzdg_amd.pyblitzdg as dg
+    from scipy.interpolate import splev, splrep
+    sys.path.insert(0, REF)
+    from swhelpers.maps import correctBCTable, makeMapsPeriodic
+    import ast
+    path = os.path.join(REF, "meshhelpers/curved.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    picked = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("adjustStraightEdges", "deformAndBlendElements")]
+    assert len(picked) == 2
+    scope = {"np": np, "splev": splev, "dg": dg}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), scope)
+
+    # the wall curve, an analytic headland between x = 3250 and x = 4750; as in the reference's mesh the straight-sided
+    # elements' wall VERTICES already lie on it (the columns of the box mesh are compressed under it)
+    length = 1500.0
+    curve = lambda t: (3250.0 + t, 1000.0 - 60.0 * np.exp(-((3250.0 + t - 4000.0) / 350.0) ** 2))   # noqa: E731
+    box = dg.MeshManager()
+    box.buildBoxMesh(nx, ny, 0.0, 8000.0, 0.0, 1000.0, shuffleSeed=seed)
+    vb = box.vertices
+    under = (vb[:, 0] >= 3250.0) & (vb[:, 0] <= 4750.0)
+    vb[under, 1] *= curve(vb[under, 0] - 3250.0)[1] / 1000.0
+    mesh = dg.MeshManager()
+    mesh.buildMesh(box.elements, vb)
+    assert np.array_equal(mesh.elements, box.elements)
+    Verts0, EToV, bc0 = mesh.vertices, mesh.elements, mesh.bcType
+    bcType = correctBCTable(bc0.copy(), EToV, Verts0, 2)
+    mesh.setBCType(bcType)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    ctx = nodes.dgContext()
+    x0, y0 = ctx.x, ctx.y
+
+    # its parametrisation: 128-point spline, 4096 samples (sw2d_curved.py:82-99)
+    ss = np.linspace(0.0, length, 4096)
+    s128 = np.linspace(0.0, length, 128)
+    splx, sply = splrep(s128, curve(s128)[0]), splrep(s128, curve(s128)[1])
+    xS, yS = splev(ss, splx, ext=2), splev(ss, sply, ext=2)
+
+    bcInds = np.where(bcType.flatten("F") > 0)
+    bcFaces = np.transpose(np.unravel_index(bcInds, (ctx.numElements, ctx.numFaces), order="F"))
+    holder = types.SimpleNamespace(x=x0.copy(), y=y0.copy(), r=ctx.r, s=ctx.s, Fmask=ctx.Fmask, numFaces=ctx.numFaces)
+    Verts1, modified, curvedFaces = scope["adjustStraightEdges"](Verts0.copy(), EToV, bcFaces, xS, yS, holder)
+    x1, y1, curvedEls = scope["deformAndBlendElements"](Verts1, EToV, curvedFaces, xS, yS, ss, splx, sply, holder, order)
+    assert len(curvedFaces) >= 3 and np.abs(x1 - x0).max() + np.abs(y1 - y0).max() > 1.0
+
+    # periodic ends: nodal maps and Gauss maps (sw2d_curved.py:120-145), on the deformed coordinates
+    nodes.setCoordinates(x1, y1)
+    gauss = nodes.buildGaussFaceNodes(2 * (order + 1))
+    assert gauss.J.min() > 0
+    bcmap = ctx.BCmap
+    vmapM, vmapP = ctx.vmapM, ctx.vmapP
+    vmapO = vmapM[np.array(bcmap[2])]
+    xFlat, yFlat = x1.flatten("F"), y1.flatten("F")
+    vM1, vP1 = makeMapsPeriodic(vmapM.copy(), vmapP.copy(), vmapO, xFlat, yFlat, xFlat[vmapO], yFlat[vmapO])
+    gmapM, gmapP = gauss.mapM, gauss.mapP
+    gxFlat, gyFlat = np.dot(gauss.Interp, x1).flatten("F"), np.dot(gauss.Interp, y1).flatten("F")
+    gmapO = np.array(gauss.BCmap[2])
+    gM1, gP1 = makeMapsPeriodic(gmapM.copy(), gmapP.copy(), gmapO, gxFlat, gyFlat, gxFlat[gmapO], gyFlat[gmapO])
+    print('rewired', (vP1 != vmapP).sum(), 'of', vmapO.size, 'nodal;', (gP1 != gmapP).sum(), 'of', gmapO.size, 'gauss')
+
+    np.savez_compressed(
+        os.path.join(HERE, f"curved_helpers_{name}.npz"), order=order, nx=nx, ny=ny, seed=seed,
+        Verts0=Verts0, EToV=EToV, bcType0=bc0, bcType=bcType, bcFaces=bcFaces, x0=x0, y0=y0, r=ctx.r, s=ctx.s, Fmask=ctx.Fmask,
+        ss=ss, xSpline=xS, ySpline=yS, splx_t=splx[0], splx_c=splx[1], sply_t=sply[0], sply_c=sply[1], spl_k=splx[2],
+        Verts1=Verts1, modifiedVerts=modified, curvedFaces=np.array(curvedFaces, dtype=np.int64), x1=x1, y1=y1,
+        curvedEls=np.array(curvedEls, dtype=np.int64),
+        vmapM=vmapM, vmapP=vmapP, vmapO=vmapO, vmapP_periodic=vP1, vmapM_periodic=vM1,
+        gmapM=gmapM, gmapP=gmapP, gmapO=gmapO, gxFlat=gxFlat, gyFlat=gyFlat, gmapP_periodic=gP1, gmapM_periodic=gM1)
+    print(f"curved_helpers_{name}.npz: K={ctx.numElements} outflow faces tagged={(bcType == 2).sum()} curved faces={len(curvedFaces)} "
+          f"max displacement={max(np.abs(x1 - x0).max(), np.abs(y1 - y0).max()):.4g} periodic nodes={vmapO.size} gauss={gmapO.size}")
+
+
 def rhsC_case(name, mesh, order, g=9.81 * 0.0025, f=7.88e-5):
     """Variant C: sw2dComputeRHS(h, hu, hv, hN, g, H, f, ctx) of the reference's sw2d.py:37-146 (reduced
     gravity and f-plane Coriolis as in its driver, :150-155), output of the reference function itself."""
@@ -487,6 +573,8 @@ def curved_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "curved":
         curved_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "curved_helpers":
+        curved_helpers_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "variant_b":
         degenerate_b_cases()
     elif len(sys.argv) > 1 and sys.argv[1] == "nodal":

@@ -232,7 +232,7 @@ def test_curved_driver_example_runs_the_reference_loop(form):
         env["BDG_SW2D_CURVED_GENERAL"] = "1"
     else:
         env.pop("BDG_SW2D_CURVED_GENERAL", None)
-    out = launch([sys.executable, os.path.join(ROOT, "examples", "sw2d_curved.py"), "box:12x8", "3", "40"], env=env, timeout=600)
+    out = launch([sys.executable, os.path.join(ROOT, "examples", "sw2d_curved.py"), "box:24x6", "3", "40"], env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "done: steps=40" in out.stdout
     assert f"nodal-trace kernels={form == 'nodal-trace'}" in out.stdout
