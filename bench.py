@@ -15,6 +15,8 @@ Prints one JSON line (rank 0): metric = element-DOF updates/s (Np*K*stages / wal
   roofline     algorithmic HBM bytes (2400 B/element/stage at N=4) over the
                average stage-kernel duration measured with HIP events on the solver's stream
   cpu_baseline the CPU oracle (port of the reference algorithm) on a bounded sample, rank 0, N=1
+  also         (default headline run only; outside its timed region) BASELINE config 5 -- 250 k triangles at N=8 -- and
+               config 3 on the seed-12345 shuffled mesh, as given and renumbered: {"config5_n8": {...}, "config3_shuffled": {...}}
 """
 import argparse
 import json
@@ -156,6 +158,43 @@ def stage_kernel_name(order, elements, affine):
     return f"sw2d_stage_affine_kernel<{order}, MODE_LSERK>"
 
 
+def also_measure(order, cells, shuffle_seed=0, keep_order=False, ramp=50, stages=20):
+    """One more configuration of BASELINE.json, measured in the same process AFTER the headline's timed region (its time
+    is not part of `value` / `ms_per_step`): build, a short untimed ramp, then `stages` fused LSERK4 stage launches timed
+    with HIP events on the solver's stream. Returns (ms per launch, elements, Np, solver flags of interest)."""
+    import blitzdg_amd.pyblitzdg as dg
+    from blitzdg_amd import sw2d
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(cells[0], cells[1], shuffleSeed=shuffle_seed)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    ctx = nodes.dgContext()
+    solver = sw2d.Sw2dSolver(nodes=nodes, g=G, device=0, flags=sw2d.KEEP_ORDER if keep_order else 0)
+    solver.setState(*initial_state(ctx.x, ctx.y))
+    dt, _ = solver.computeDt(CFL)
+    solver.timeLSERK4Stages(dt, ramp)
+    ms = solver.timeLSERK4Stages(dt, stages)
+    solver.computeDt(CFL)  # raises if the run blew up
+    return ms, ctx.numElements, ctx.numLocalPoints, solver.isRenumbered, solver.usesAffineGeometry
+
+
+def also_block():
+    """BASELINE.md section 3 rows C5 and C3-shuffled beside the headline (C3, natural order) in the driver's ONE line:
+    250 k triangles at N=8 on the matrix-core kernel, and the seed-12345 shuffled 10^6-triangle mesh at N=4, once in the
+    caller's order (BDG_SW2D_KEEP_ORDER) and once with the solver's automatic renumbering."""
+    out = {}
+    ms, K, Np, _, affine = also_measure(8, (500, 250))
+    gbps = algorithmic_bytes_per_element(8) * K / (ms * 1e-3) / 1e9
+    out["config5_n8"] = {"ms": ms, "elements": K, "order": 8, "updates_per_s": Np * K / (ms * 1e-3), "achieved_GBps": gbps,
+                         "frac": gbps / HBM_PEAK_GBPS, "kernel": stage_kernel_name(8, K, affine), "stages_timed": 20}
+    ms_given, K, Np, renum_given, _ = also_measure(4, (1000, 500), shuffle_seed=12345, keep_order=True)
+    ms_renum, _, _, renum, affine = also_measure(4, (1000, 500), shuffle_seed=12345)
+    gbps = algorithmic_bytes_per_element(4) * K / (ms_renum * 1e-3) / 1e9
+    out["config3_shuffled"] = {"ms_as_given": ms_given, "ms_renumbered": ms_renum, "elements": K, "order": 4, "seed": 12345,
+                               "renumbered_internally": [renum_given, renum], "updates_per_s_renumbered": Np * K / (ms_renum * 1e-3),
+                               "frac_renumbered": gbps / HBM_PEAK_GBPS, "kernel": stage_kernel_name(4, K, affine), "stages_timed": 20}
+    return out
+
+
 def run_single(args):
     os.environ.setdefault("OMP_NUM_THREADS", str(min(32, os.cpu_count() or 8)))
     import blitzdg_amd.pyblitzdg as dg
@@ -239,6 +278,10 @@ def run_single(args):
                      "measured_stream_triad_GBps": triad, "same_access_pattern_no_compute_ms": probe_ms,
                      "kernel": stage_kernel_name(ORDER, K, solver.usesAffineGeometry)},
     }
+    headline = ORDER == 4 and (NX, NY) == (1000, 500) and not (args.shuffle_seed or args.reorder or args.nodal_geometry)
+    if headline and not args.no_also and not os.environ.get("BDG_SW2D_AFFINE_VARIANT"):
+        del solver              # (its 2.6 GB are not needed beside the next meshes)
+        line["also"] = also_block()
     if not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(ORDER)
     print(json.dumps(line), flush=True)
@@ -427,6 +470,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-clock-ramp", action="store_true", help="skip the untimed clock-ramp blocks")
+    ap.add_argument("--no-also", action="store_true", help="skip the untimed extra configurations (config 5, config 3 shuffled)")
     ap.add_argument("--order", type=int, default=ORDER, help="polynomial order (default: the BASELINE metric's N=4)")
     ap.add_argument("--cells", default=f"{NX}x{NY}", help="box cells NXxNY, 2 triangles each (default 1000x500)")
     ap.add_argument("--shuffle-seed", type=int, default=0, help="Fisher-Yates element shuffle (adversarial ordering)")

@@ -13,7 +13,7 @@ OUT=$R/gpurun_out
 mkdir -p "$OUT"
 rm -rf "$OUT"/prof_${TAG}_*   # stale CSVs from earlier collections would be averaged in
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --no-cpu-baseline $EXTRA"
+BENCH="python3 $R/bench.py --no-cpu-baseline --no-also $EXTRA"
 $BENCH --steps 200 --warmup 20 > "$OUT/prof_${TAG}_warm.log" 2>&1   # a fresh box ramps its clocks during the first run
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_trace" -- $BENCH --steps 200 --warmup 20 > "$OUT/prof_${TAG}_trace.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/prof_${TAG}_fetch" -- $BENCH --steps 20 --warmup 5 > "$OUT/prof_${TAG}_fetch.log" 2>&1

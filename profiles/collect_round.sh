@@ -23,7 +23,7 @@ bash profiles/collect_curved.sh ${TAG}_curved_n8 8 250 120 > "$OUT/collect_curve
 for n in 4 5 6 7 8; do
   cells=$([ $n = 4 ] && echo 1000x500 || ([ $n = 5 ] && echo 800x400 || ([ $n = 6 ] && echo 1000x250 || echo 500x250)))
   BDG_REHEARSE_RANKS=0,1,4 python3 bench.py --rehearse-world 8 --steps 40 --warmup 10 --order $n --cells $cells 2>/dev/null | grep '^{'
-  python3 bench.py --order $n --cells $cells --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | grep '^{'
+  python3 bench.py --order $n --cells $cells --steps 100 --warmup 20 --no-cpu-baseline --no-also 2>/dev/null | grep '^{'
 done > "$OUT/rehearsal.jsonl"
 for n in 4 2; do w=$n; done
 for w in 4 2; do BDG_REHEARSE_RANKS=0,1 python3 bench.py --rehearse-world $w --steps 40 --warmup 10 2>/dev/null | grep '^{'; done > "$OUT/rehearsal_n4_w42.jsonl"

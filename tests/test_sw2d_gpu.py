@@ -245,6 +245,9 @@ def test_medium_box_meshes_vs_oracle(order, nx, ny, seed):
             assert relmax(a, b) < STATE_TOL
 
 
+LAKE_FACTOR = 4.0   # measured max|RHS| of the lake at rest in units of eps g h^2/2 (N+1)^2 max|metric|: see the test's print
+
+
 @pytest.mark.parametrize("N,nx,ny", [(4, 1000, 500), (8, 500, 250)], ids=["config3_N4_1M", "config5_N8_250k"])
 def test_full_size_properties(N, nx, ny):
     """BASELINE config 3 size (1000 x 500 cells = 10^6 triangles, N=4) and config 5 size (500 x 250 cells = 250 000
@@ -268,7 +271,14 @@ def test_full_size_properties(N, nx, ny):
     flat = np.full((Np, K), 10.0)
     z = np.zeros((Np, K))
     r = s.computeRHS(flat, z, z)
-    assert max(np.abs(a).max() for a in r) < (1e-9 if N <= 4 else 1e-8) * 490.5   # g h^2 / 2 = 490.5; 1 / element size and N^2 amplify round-off
+    # Round-off of a constant pressure flux g h^2 / 2 = 490.5 through the differentiation matrices: their rows sum to zero only to
+    # eps * (N + 1)^2 (the size of their entries), times the metric 2 / (element size). The bound is that estimate from THIS mesh
+    # with a factor 4 (measured on the GPU: see LAKE_FACTOR below), so that a tenfold loss of accuracy at 10^6 elements fails.
+    metric = max(np.abs(t).max() for t in (ctx.rx, ctx.sx, ctx.ry, ctx.sy))
+    lake_bound = LAKE_FACTOR * np.finfo(float).eps * 490.5 * (N + 1) ** 2 * metric
+    lake = max(np.abs(a).max() for a in r)
+    print(f"lake at rest, N={N}: max|RHS| = {lake:.3e} = {lake / (lake_bound / LAKE_FACTOR):.2f} x eps g h^2/2 (N+1)^2 max|metric|")
+    assert lake < lake_bound, (lake, lake_bound)
     s.setState(flat, z, z)
     dt_rest, _ = s.computeDt(0.65)
     s.stepLSERK4(dt_rest, 2)
