@@ -222,7 +222,12 @@ def test_contexts_without_face_structure_fall_back_to_the_general_form(form):
 def test_curved_driver_example_runs_the_reference_loop(form):
     """examples/sw2d_curved.py = the reference's sw2d_curved.py driver (curved wall, periodic ends, wall-layer drag, tracer,
     RK2 + filter) on this repository's API: 40 steps stay finite, the periodic rewiring keeps the nodal-trace kernels,
-    the tracer stays within its initial bounds to the filter's overshoot, mass drifts by round-off times steps only."""
+    the tracer stays within its initial bounds to the filter's overshoot. Mass: the reference's own helpers leave the mesh slightly
+    non-conforming along the curved wall (adjustStraightEdges snaps a wall vertex onto the nearest of 4096 spline samples for the
+    elements that have a wall FACE there, while the elements that touch the wall in that vertex only keep the old position, and
+    deformAndBlendElements does not move a face's end node with vr = 1: gaps of a fraction of a sample spacing, 0.1 m in 8 km), so
+    the total mass is conserved to that, not to round-off (measured 4e-7 over 40 steps; a conforming mesh gives 1e-13, as the
+    partitioned-solver tests of this file check)."""
     import re
     import sys
 
@@ -237,7 +242,7 @@ def test_curved_driver_example_runs_the_reference_loop(form):
     assert "done: steps=40" in out.stdout
     assert f"nodal-trace kernels={form == 'nodal-trace'}" in out.stdout
     drift = float(re.findall(r"mass drift=([-+.\deE]+)", out.stdout)[-1])
-    assert abs(drift) < 1e-9
+    assert abs(drift) < 5e-6
     lo, hi = (float(v) for v in re.findall(r"N in \[([-+.\deE]+), ([-+.\deE]+)\]", out.stdout)[-1])
     assert -0.05 < lo and hi < 1.05
 
