@@ -24,6 +24,7 @@
 #include <cstring>
 #include <limits>
 #include <queue>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -243,6 +244,13 @@ struct bdg_sw2d {
     hipEvent_t evPacked[2] = {nullptr, nullptr}, evCopied[2] = {nullptr, nullptr}; // in-process group transport
     bool localGroup = false;
     DevBuf<double> sendBuf, recvBuf, scalarBuf;
+    // In-kernel dependencies between the two chains of an exchanged stage (round 4): two device counters --
+    // [0] ring tiles of interior launches finished, [1] workgroups of boundary launches finished, [2] a word a bounded wait
+    // sets when it gives up -- and what the host expects them to reach after the launches issued so far
+    DevBuf<unsigned long long> syncBuf;
+    unsigned long long expectRing = 0, expectStrip = 0;
+    int ringBegin = 0;   // first interior element that has a partition-boundary neighbour (elements are ordered [deep | ring | boundary | ghost]
+                         // by halo.build_plan; any other order only makes more tiles wait)
     double* fscaleNodal = nullptr; // (NFN, ld) per-node Fscale plane (time-step reduction)
     double* qcur = nullptr;  // current state
     double* qalt = nullptr;  // the other buffer
@@ -309,7 +317,12 @@ struct bdg_sw2d {
         // instead of 64 (measured at N=4: 750 elements 7 us vs 19 us; 125 k elements 48 us vs 56 us;
         // 250 k elements 136 us vs 109 us -- DESIGN.md section 4).
         int variant = affineVariant;
-        if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < kSmallLaunch[N]) variant = 5;
+        // BDG_SW2D_SMALL_LAUNCH=n pins the crossover (A/B runs; the partition-boundary strip keeps the table's value: halosFold)
+        static const int smallPinned = [] { const char* e = std::getenv("BDG_SW2D_SMALL_LAUNCH"); return e ? std::atoi(e) : -1; }();
+        const int smallLaunch = (smallPinned >= 0 && p.kbegin == 0) ? smallPinned : kSmallLaunch[N];
+        if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < smallLaunch) variant = 5;
+        if (p.syncSignal && !(affine && !variantB && !variantD && (variant == 5 || variant == 7)))
+            throw std::logic_error("in-kernel stage dependencies were requested for a launch that is not on a matrix-core kernel");
         if (!affine && (variantB || variantD)) {
             // per-node geometry tables: the general (rolled) form of variants B / C / D
             buildNodalVariantOps();
@@ -417,6 +430,10 @@ struct bdg_sw2d {
             if (stateOnceSrc && kt->mfma3SrcFields >= nf && !std::getenv("BDG_SW2D_TRACER_PASS") &&
                 static_cast<long long>(nf) * Np * ld * 8 <= 4294967295LL) {
                 hipCheck(kt->stageMfma2Src(mode, p, ph, nf == 4 ? 5 : 4, st), what);
+            } else if (stateOnceSrc && kt->mfma3TracerPhase && nf == 4 && !std::getenv("BDG_SW2D_TRACER_PASS") &&
+                       static_cast<long long>(4) * Np * ld * 8 <= 4294967295LL) {
+                // N = 8: the tracer equation as a second phase of every tile, from the state tile still in LDS (one launch, state read once)
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 7, st), what);
             } else if (stateOnceSrc && kt->mfma3SrcFields == 3 && nf == 4 && static_cast<long long>(3) * Np * ld * 8 <= 4294967295LL) {
                 // N = 8: three conserved fields with sources on the state-once schedule, the tracer in its own pass
                 hipCheck(kt->stageMfma2Src(mode, p, ph, 4, st), what);
@@ -512,10 +529,17 @@ struct bdg_sw2d {
     //       1 = partition-boundary elements, then advance; 2 = all owned elements, then advance.
     // done: an event to record when this launch has finished -- through the launch itself where its helper can (one packet
     // on the queue instead of two), by a record behind it otherwise
-    void launchLserkStage(int part = 2, hipStream_t on = nullptr, bool advance = true, hipEvent_t done = nullptr) {
+    void launchLserkStage(int part = 2, hipStream_t on = nullptr, bool advance = true, hipEvent_t done = nullptr, bool flagSync = false) {
         const int s = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
         bdg_dev::StageParams p = baseParams();
         bool recorded = false;
+        unsigned signals = 0;
+        if (flagSync && part == 0) { // ring tiles wait for every boundary launch issued so far and signal for themselves
+            p.syncWait = syncBuf.p + 1; p.syncWaitValue = expectStrip;
+            p.syncSignal = syncBuf.p; p.syncError = reinterpret_cast<unsigned int*>(syncBuf.p + 2);
+            p.syncFirstTile = ringBegin / 16;
+            p.syncSignalsOut = &signals;
+        }
         static const bool extLaunch = [] { const char* e = std::getenv("BDG_SW2D_EXT_LAUNCH"); return !e || e[0] != '0'; }();
         if (done && extLaunch) { p.stopEvent = done; p.stopEventUsed = &recorded; }
         if (part == 0) {
@@ -533,6 +557,7 @@ struct bdg_sw2d {
         const bool lastOfStep = s == blitzdg::LSERK4::numStages - 1;
         nextEvalTime = lastOfStep ? timeNow + dtStage : timeNow;
         launchStage(bdg_dev::MODE_LSERK, false, p, "sw2d stage kernel <LSERK>", on);
+        expectRing += signals;
         if (done && !recorded) hipCheck(hipEventRecord(done, on ? on : stream), "hipEventRecord");
         if (part == 0 || !advance) return;
         std::swap(qcur, qalt);
@@ -616,11 +641,42 @@ struct bdg_sw2d {
         if (!haloFusable || !affine || variantB || variantD || variantForced || std::getenv("BDG_SW2D_HALO_KERNELS")) return false;
         return N >= 5 || numOwned - numInterior < kSmallLaunch[N]; // the strip runs on a matrix-core kernel
     }
+    // True when the two chains of an exchanged stage can meet through device counters polled inside the kernels instead of
+    // through events on the queues (BDG_SW2D_EVENT_SYNC=1 keeps the events): folded halo staging, and both launches of a stage
+    // on kernels that have a SYNC instance -- the interior on the matrix-core kernel of its order, the strip on the latency form.
+    bool flagSyncUsable() const {
+        const char* eventsPinned = std::getenv("BDG_SW2D_EVENT_SYNC"); // (read per call: the tests switch it within one process)
+        if ((eventsPinned && eventsPinned[0] != '0') || !syncBuf.p || !halosFold()) return false;
+        if (std::getenv("BDG_SW2D_STRIP_THROUGHPUT") || std::getenv("BDG_SW2D_HALO_VARIANT")) return false;
+        if (N >= 5) return affineVariant == 7 && (numOwned - numInterior + 15) / 16 <= 1024;
+        static const int smallPinned = [] { const char* e = std::getenv("BDG_SW2D_SMALL_LAUNCH"); return e ? std::atoi(e) : -1; }();
+        return numInterior > 0 && numInterior < (smallPinned >= 0 ? smallPinned : kSmallLaunch[N]);
+    }
+    // a bounded in-kernel wait that gave up (sync_wait) left a mark: report it the next time the host looks at the device
+    void checkSyncError() {
+        if (!syncBuf.p) return;
+        unsigned long long mark = 0;
+        hipCheck(hipMemcpy(&mark, syncBuf.p + 2, sizeof(mark), hipMemcpyDeviceToHost), "sync word download");
+        if (mark != 0) {
+            hipCheck(hipMemset(syncBuf.p + 2, 0, sizeof(mark)), "hipMemset");
+            throw std::runtime_error("an in-kernel wait between the interior and the partition-boundary launch of an exchanged stage "
+                                     "timed out: the results of this run are not valid (BDG_SW2D_EVENT_SYNC=1 restores event waits)");
+        }
+    }
     // LSERK4 stage of the partition-boundary elements: reads ghost traces from recv, writes send records
-    void launchBoundaryStageFolded(hipStream_t on, const double* recv, double* send, hipEvent_t done = nullptr) {
+    // ringExpected (flagSync): the ring-tile count the interior launch of the PREVIOUS stage brings the counter to
+    void launchBoundaryStageFolded(hipStream_t on, const double* recv, double* send, hipEvent_t done = nullptr, bool flagSync = false,
+                                   unsigned long long ringExpected = 0) {
         const int st = static_cast<int>(stageCount % blitzdg::LSERK4::numStages);
         bdg_dev::StageParams p = baseParams();
         bool recorded = false;
+        unsigned signals = 0;
+        if (flagSync) {
+            p.syncWait = syncBuf.p; p.syncWaitValue = ringExpected;
+            p.syncSignal = syncBuf.p + 1; p.syncError = reinterpret_cast<unsigned int*>(syncBuf.p + 2);
+            p.syncFirstTile = 0;
+            p.syncSignalsOut = &signals;
+        }
         static const bool extLaunch = [] { const char* e = std::getenv("BDG_SW2D_EXT_LAUNCH"); return !e || e[0] != '0'; }();
         if (done && extLaunch) { p.stopEvent = done; p.stopEventUsed = &recorded; }
         p.kbegin = numInterior;
@@ -637,6 +693,7 @@ struct bdg_sw2d {
             p.opsAffine = opsMfma.p;
             hipCheck(kt->stageMfmaHalo(p, on), "sw2d boundary stage kernel <LSERK, halo>");
         }
+        expectStrip += signals;
         if (done && !recorded) hipCheck(hipEventRecord(done, on), "hipEventRecord");
         std::swap(qcur, qalt);
         ++stageCount;
@@ -670,12 +727,25 @@ struct bdg_sw2d {
         // With the staging folded into the boundary kernel, chain B is: exchange -> boundary kernel (which reads
         // the received records and writes the next send records); only the very first exchange needs a pack.
         const bool fold = halosFold();
+        // Round 4: where both launches of a stage have a SYNC instance the two chains meet INSIDE the kernels. The elements are
+        // ordered [deep interior | ring | boundary | ghost]; only the ring -- the interior elements next to the partition
+        // boundary -- reads what boundary(s-1) wrote and overwrites what it read, and only the boundary elements read what the ring
+        // tiles of interior(s-1) wrote. So interior(s)'s ring tiles (its last ones) poll a counter that boundary(s-1)'s workgroups
+        // raise, boundary(s) polls the counter interior(s-1)'s ring tiles raise, and neither queue carries a wait or a record
+        // for the other any more: the interior launches run back to back on A, exchange and boundary launch back to back on B.
+        // No deadlock: a launch only ever waits for a launch that was queued earlier on the other stream and whose own waits
+        // are for launches queued earlier still (down to counts that already hold when the loop starts); the waiting ring tiles
+        // are a few dozen waves, so the boundary launch and RCCL's kernel always find free compute units (interiorGridCap keeps
+        // them free at N >= 5), and every wait is bounded (sync_wait) -- a wave that gives up marks the run invalid.
+        const bool flags = fold && flagSyncUsable();
         if (fold) launchPack(sendBuf.p, commStream);
         for (int i = 0; i < numStages; ++i) {
             const int cur = i & 1, prev = cur ^ 1;
+            const bool last = i == numStages - 1;
+            const unsigned long long ringBefore = expectRing; // what interior(i-1) and everything before it brings the counter to
             // ---- chain A
-            if (haveB) hipCheck(hipStreamWaitEvent(stream, evB[prev], 0), "hipStreamWaitEvent");
-            launchLserkStage(0, nullptr, true, evA[cur]);
+            if (!flags && haveB) hipCheck(hipStreamWaitEvent(stream, evB[prev], 0), "hipStreamWaitEvent");
+            launchLserkStage(0, nullptr, true, flags ? nullptr : evA[cur], flags);
             // ---- chain B
             if (!fold) launchPack(sendBuf.p, commStream);
             if (!peers.empty()) {
@@ -694,8 +764,8 @@ struct bdg_sw2d {
                 ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
             }
             if (!fold) launchUnpack(recvBuf.p, commStream);
-            if (haveA) hipCheck(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
-            if (fold) launchBoundaryStageFolded(commStream, recvBuf.p, sendBuf.p, evB[cur]);
+            if (!flags && haveA) hipCheck(hipStreamWaitEvent(commStream, evA[prev], 0), "hipStreamWaitEvent");
+            if (fold) launchBoundaryStageFolded(commStream, recvBuf.p, sendBuf.p, (!flags || last) ? evB[cur] : nullptr, flags, ringBefore);
             else launchLserkStage(1, commStream, true, evB[cur]); // partition-boundary elements, advance
             haveA = haveB = true;
         }
@@ -1377,6 +1447,7 @@ int bdg_sw2d_get_state(bdg_sw2d* s, double* h, double* hu, double* hv) {
         s->downloadRows(s->qcur, h, s->Np);
         s->downloadRows(s->qcur + pl, hu, s->Np);
         s->downloadRows(s->qcur + 2 * pl, hv, s->Np);
+        s->checkSyncError();
     });
 }
 
@@ -1684,6 +1755,7 @@ int bdg_sw2d_synchronize(bdg_sw2d* s) {
         requireSolver(s, "bdg_sw2d_synchronize");
         s->use();
         hipCheck(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+        s->checkSyncError();
     });
 }
 
@@ -1724,6 +1796,23 @@ int bdg_sw2d_set_partition(bdg_sw2d* s, int num_interior, int num_owned, const i
         s->numInterior = num_interior;
         s->numOwned = num_owned;
         s->numSend = num_send;
+        // the first interior element with a partition-boundary neighbour: interior tiles from there on read what the boundary
+        // launch of the previous stage writes (and overwrite what it reads); tiles before it depend on interior elements only
+        {
+            const int NFN = s->NFN;
+            std::vector<int> vm(static_cast<size_t>(NFN) * s->ld);
+            hipCheck(hipMemcpy(vm.data(), s->vmapP.p, vm.size() * sizeof(int), hipMemcpyDeviceToHost), "gather table download");
+            int ring = num_interior;
+            for (int jf = 0; jf < NFN && ring > 0; ++jf) {
+                const int* row = vm.data() + static_cast<size_t>(jf) * s->ld;
+                for (int k = 0; k < ring; ++k) {
+                    const int id = row[k];
+                    const long long slot = static_cast<long long>(id < 0 ? -(id + 1) : id) % s->ld;
+                    if (slot >= num_interior && slot < num_owned) { ring = k; break; }
+                }
+            }
+            s->ringBegin = ring;
+        }
         // for the boundary kernel with the halo staging folded in: the (up to three) send records of each
         // partition-boundary element
         const int nB = num_owned - num_interior;
@@ -1856,6 +1945,9 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
         s->scalarBuf.alloc(2, s->bytes);
+        s->syncBuf.alloc(8, s->bytes);
+        hipCheck(hipMemset(s->syncBuf.p, 0, 8 * sizeof(unsigned long long)), "hipMemset");
+        s->expectRing = s->expectStrip = 0;
     });
 }
 
@@ -2045,6 +2137,7 @@ int bdg_sw2d_barrier(bdg_sw2d* s) {
         s->use();
         hipCheck(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
         if (s->commStream) hipCheck(hipStreamSynchronize(s->commStream), "hipStreamSynchronize");
+        s->checkSyncError();
         (void)s->allReduceScalar(0.0, true); // every rank arrives before anyone leaves
         hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
     });

@@ -90,12 +90,60 @@ struct StageParams {
     int stagger;
     // profiling builds (-DBDG_PHASE_CLOCK): 16 cycle counts per wave (LDS copy, k-steps, surface, update), else unused
     unsigned long long* phaseClock;
+    // In-kernel dependencies between the two chains of a partitioned stage (round 4; SYNC instances of the matrix-core kernels,
+    // DESIGN.md section 4): the tiles from syncFirstTile on (interior launches: the ring of elements next to the partition
+    // boundary, ordered last; strip launches: every tile, syncFirstTile = 0) wait until *syncWait >= syncWaitValue before
+    // anything of theirs is read or written, and add one to *syncSignal when their stores are visible device-wide
+    // (interior: one per ring tile, strip: one per workgroup). A wait that does not end within the spin bound sets
+    // *syncError and goes on (the host reports it): no wave can hang the device.
+    const unsigned long long* syncWait;
+    unsigned long long syncWaitValue;
+    unsigned long long* syncSignal;
+    unsigned int* syncError;
+    int syncFirstTile;
+    unsigned int* syncSignalsOut; // host side only: the launch helper stores the number of signals the launch will add
     // host side only (the launch helpers of sw2d_order.hip): when set, the launch records this event through its own completion
     // signal (hipExtLaunchKernelGGL) instead of a separate record packet behind it, and sets *stopEventUsed; a launch path that
     // does not look at it leaves the flag alone and the caller records the event itself
     hipEvent_t stopEvent;
     bool* stopEventUsed;
 };
+
+// ---- hand-off between concurrently running kernels of one device (the guide's valid form, MI355X_MICROARCH.md, inter-workgroup
+// visibility: per-XCD L2s are not coherent with each other and a CU's L1 is never refreshed by another CU's stores).
+// Consumer: relaxed agent-scope polls of the counter, then ONE agent-scope acquire (invalidates this CU's L1; the waiting wave's
+// own later loads are ordered behind it). Bounded: after kSyncSpinLimit polls the wave sets *err and goes on.
+constexpr unsigned kSyncSpinLimit = 1u << 21;
+__device__ __forceinline__ void sync_wait(const unsigned long long* ctr, unsigned long long want, unsigned int* err) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > kSyncSpinLimit) {
+            if (err) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+// Producer, one wave for its own stores: drain them, write back this XCD's dirty L2 lines (agent-scope release), drain again
+// (the compiler may drop the wait behind the write-back when it thinks the scoreboard is empty: inline asm is invisible to that
+// pass), then one lane adds to the counter.
+__device__ __forceinline__ void sync_signal_wave(unsigned long long* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Producer, one workgroup for all its waves' stores (every wave calls this at the end of the kernel).
+__device__ __forceinline__ void sync_signal_workgroup(unsigned long long* ctr) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):
 // hu /= (1 + sigma hu^2), applied to the momentum components after a stage update.

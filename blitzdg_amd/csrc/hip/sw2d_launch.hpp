@@ -41,6 +41,7 @@ struct KernelTable {
     // (sw2d_mfma3src_kernel.hpp; hipErrorNotSupported where its LDS tiles or registers do not fit: see mfma3SrcFields)
     hipError_t (*stageMfma2Src)(int mode, const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream);
     int mfma3SrcFields; // 0: no state-once kernel with sources at this order; else the number of fields it takes (up to)
+    int mfma3TracerPhase; // 1: tracer = 7 exists -- the three-field state-once kernel with the tracer equation as a second phase of every tile (N = 8)
     // variant D (tracer + sources), straight-sided elements, nf = 3 or 4 waves per 64 elements
     int vdOpsDoubles;
     hipError_t (*stageVd)(int mode, const StageParams& p, const VdParams& vp, hipStream_t stream);

@@ -95,9 +95,15 @@ struct Mfma3Lds {
 // NFILT (NODAL only): the result is Filter * RHS. With the metric applied after the differentiation the filter cannot be
 // folded into the operators (Filter (rx o Dr F) != rx o (Filter Dr) F): the image carries MT KV Filter tiles behind the
 // plain operators, and the finished RHS -- accumulator layout = operand layout -- goes through one more product.
-template <int N, int MODE, bool HALO = false, bool NODAL = false, bool NFILT = false>
+// SYNC (interior launches of a partitioned stage, StageParams::syncWait ...): the tiles from syncFirstTile on -- the ring of
+// elements next to the partition boundary, ordered last -- are not requested, read or written before the previous stage's
+// boundary launch has signalled, and each signals when its stores are visible device-wide (sw2d_kernels.hpp: sync_wait,
+// sync_signal_wave). Everything of a tile is requested a tile ahead, so a wave checks before it starts the tile in front of its
+// first ring tile.
+template <int N, int MODE, bool HALO = false, bool NODAL = false, bool NFILT = false, bool SYNC = false>
 __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StageParams p) {
     static_assert(!HALO || MODE == MODE_LSERK, "halo staging is folded into LSERK stages only");
+    static_assert(!SYNC || (MODE == MODE_LSERK && !HALO && !NODAL), "in-kernel stage dependencies: interior launches of LSERK stages");
     static_assert(!(HALO && NODAL), "partitioned runs use the straight-sided form");
     static_assert(NODAL || !NFILT, "straight-sided elements take the filter through pre-multiplied operators");
     using E = Elem<N>;
@@ -244,6 +250,16 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
         const unsigned naps = (blk & 7u) * static_cast<unsigned>(p.stagger);
         for (unsigned i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
     }
+    bool synced = false;
+    auto waitBefore = [&](unsigned upcoming) { // `upcoming`: a tile of this wave whose data is about to be requested
+        if constexpr (SYNC) {
+            if (!synced && upcoming < tileEnd && upcoming >= static_cast<unsigned>(p.syncFirstTile)) {
+                sync_wait(p.syncWait, p.syncWaitValue, p.syncError);
+                synced = true;
+            }
+        }
+    };
+    waitBefore(tile);
     bool live;
     unsigned k = elementOf(tile, live);
     double qB[3][KV], geo[13], hP[3][KF], huP[3][KF], hvP[3][KF];
@@ -270,6 +286,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
     for (;;) {
         const unsigned v8 = (q * static_cast<unsigned>(ld) + k) * 8u;
         const bool more = tile + tileStep < tileEnd;
+        waitBefore(tile + tileStep); // the next tile is requested during this one
         bool liveN = false;
         const unsigned kN = more ? elementOf(tile + tileStep, liveN) : k;
         if constexpr (!PF) loadTile(k);
@@ -583,6 +600,9 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
             for (int r = 0; r < MT; ++r) updateBlock(r);
         }
         BDG_STAMP(15) // update and stores
+        if constexpr (SYNC) {
+            if (tile >= static_cast<unsigned>(p.syncFirstTile)) sync_signal_wave(p.syncSignal);
+        }
         if (!more) break;
         tile += tileStep;
         k = kN;
@@ -627,7 +647,9 @@ namespace bdg_dev {
 // third of the matrix instructions, in the same order as sw2d_stage_mfma3_kernel (volume k-steps, then faces), and
 // does its own field's stage update, halo staging included (ghost traces from the received records, new state to the
 // send records). The wave speed of a face needs all three fields, so traces are loaded by all three waves (L1 hits).
-template <int N>
+// SYNC: the launch waits at its top for the previous interior launch's ring tiles (the boundary elements' interior
+// neighbours, whose new state it reads and whose old state it overwrites) and signals once per workgroup at its end.
+template <int N, bool SYNC = false>
 __global__ __launch_bounds__(192, 2) void sw2d_strip_mfma3_kernel(const StageParams p) {
     using E = Elem<N>;
     using O = MfmaOps2<N>;
@@ -635,6 +657,7 @@ __global__ __launch_bounds__(192, 2) void sw2d_strip_mfma3_kernel(const StagePar
 
     extern __shared__ double sOps[];
     bool staged = false; // the operator image is staged AFTER the first tile's loads are requested (below)
+    if constexpr (SYNC) sync_wait(p.syncWait, p.syncWaitValue, p.syncError);
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
     const int c = __builtin_amdgcn_readfirstlane(static_cast<int>(threadIdx.x >> 6)); // field of this wave
@@ -821,6 +844,7 @@ __global__ __launch_bounds__(192, 2) void sw2d_strip_mfma3_kernel(const StagePar
             }
         }
     }
+    if constexpr (SYNC) sync_signal_workgroup(p.syncSignal);
 }
 
 } // namespace bdg_dev

@@ -16,12 +16,19 @@
 // N = 8 (three fields only: four fields' state tiles would not fit the LDS beside the operators): nothing of the next tile
 // is requested ahead -- it would not fit the registers, and a spilled register costs more than an exposed round trip.
 // PHYS = 2: the stage kernel of variant B (the reference's tidal driver), see the template's comment.
+// TPHASE (round 4; N = 8, where four fields' operands, accumulators and traces do not fit one wave's registers): the tracer
+// equation as a SECOND PHASE of every tile, in the same launch. Phase one is the three-field kernel unchanged; when its last
+// row block is stored the tile's h, hu, hv are still in the wave's LDS tile, so the tracer's volume operands (hN u, hN v) and
+// its '-' traces come from there -- no second read of the state from HBM, which is what the separate tracer pass of rounds
+// 2-3 cost (a launch that re-read h, hu, hv and took as long as the three conserved fields together). The neighbours' traces
+// are gathered again (the registers that held them were given up to phase one's face products; these are L2 hits: a sibling
+// wave streamed those rows moments ago). LDS: operators + F' tiles 69 KB + four waves x four fields x 5.6 KB = 157.5 KB.
 #pragma once
 #include "sw2d_mfma3_kernel.hpp"
 
 namespace bdg_dev {
 
-template <int N, bool TRACER>
+template <int N, bool TRACER>   // TRACER: four fields in the wave's state tile (fused tracer, or the tracer as a second phase)
 struct Mfma3SrcLds {
     using O = MfmaOps2<N>;
     static constexpr int NF = TRACER ? 4 : 3;
@@ -35,13 +42,15 @@ struct Mfma3SrcLds {
 // element) take the tide elevation, hydrostatic-reconstruction star states, the GLOBAL Lax-Friedrichs speed (a device
 // scalar reduced beforehand), sources with the depth gradient (slope = +1, dragSign = -1), and in combine steps the
 // per-node sponge coefficient. No tracer.
-template <int N, int MODE, bool TRACER, int PHYS = 1>
+template <int N, int MODE, bool TRACER, int PHYS = 1, bool TPHASE = false>
 __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const StageParams p, const PhysParams ph) {
     static_assert(PHYS == 1 || (PHYS == 2 && !TRACER), "variant B has three fields");
+    static_assert(!TPHASE || (PHYS == 1 && !TRACER), "the tracer phase follows the three-field form of variants C / D");
     using E = Elem<N>;
     using O = MfmaOps2<N>;
-    using L = Mfma3SrcLds<N, TRACER>;
-    constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF, NF = L::NF;
+    using L = Mfma3SrcLds<N, TRACER || TPHASE>;
+    constexpr int Np = E::Np, Nfp = E::Nfp, MT = O::MT, KV = O::KV, KF = O::KF, NF = TRACER ? 4 : 3;
+    constexpr int NFD = (TRACER || TPHASE) ? 4 : 3;   // planes behind the state / residual / output descriptors
     constexpr int IMAGE = L::IMAGE, OFF_F = O::DOUBLES;
     // N = 8: nothing of the next tile is requested ahead (it would not fit the registers, and a spilled register's reload
     // drains the memory pipeline); the tile's own data is requested at its top: one exposed round trip per tile
@@ -68,9 +77,9 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
     const unsigned planeBytes = static_cast<unsigned>(plane * 8), ld8 = static_cast<unsigned>(ld) * 8u, ld4 = static_cast<unsigned>(ld) * 4u;
     // one descriptor per array, the field picked by the scalar offset (an array of NF planes stays below 4 GiB: checked
     // by the launcher); the source tables get an empty descriptor when absent
-    const __amdgpu_buffer_rsrc_t rq = plane_rsrc(p.qin, NF * planeBytes),
-                                 rold = plane_rsrc(MODE == MODE_LSERK ? p.res : (MODE == MODE_COMBINE ? p.qbase : p.qin), NF * planeBytes),
-                                 rout = plane_rsrc(MODE == MODE_RHS ? p.rhs : p.qout, NF * planeBytes),
+    const __amdgpu_buffer_rsrc_t rq = plane_rsrc(p.qin, NFD * planeBytes),
+                                 rold = plane_rsrc(MODE == MODE_LSERK ? p.res : (MODE == MODE_COMBINE ? p.qbase : p.qin), NFD * planeBytes),
+                                 rout = plane_rsrc(MODE == MODE_RHS ? p.rhs : p.qout, NFD * planeBytes),
                                  rgeo = plane_rsrc(p.ageo, 13u * ld8), ridx = plane_rsrc(p.vmapP, 3u * Nfp * ld4),
                                  rsx = plane_rsrc(ph.sx ? ph.sx : p.ageo, ph.sx ? planeBytes : 0u),
                                  rsy = plane_rsrc(ph.sy ? ph.sy : p.ageo, ph.sy ? planeBytes : 0u),
@@ -358,6 +367,128 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                 }
             __builtin_amdgcn_sched_barrier(0);
             updateBlock(r);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        // ---- TPHASE: the tracer equation of this tile (F4 = hN u, G4 = hN v, Lax-Friedrichs with the flow's speed, no sources;
+        //      swhelpers/flux.py:17-19, rhs.py:253-258) from the state tile that is still in LDS
+        if constexpr (TPHASE) {
+            const unsigned f3 = 3u * planeBytes;
+            double qT[KV], old4[KV], tq[4][3][KF];
+#pragma unroll
+            for (int t = 0; t < KV; ++t) qT[t] = bld_f64(rq, row_voffset<Np, KV>(t, q, v8), f3 + static_cast<unsigned>(4 * t) * ld8);
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int tf = 0; tf < KF; ++tf) {
+                    const int n = 4 * tf + static_cast<int>(q);
+                    const int id = n < Nfp ? fidx[f][tf] : 0;
+                    const unsigned o8 = static_cast<unsigned>(id < 0 ? -(id + 1) : id) * 8u;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tq[c][f][tf] = bld_f64(rq, o8, static_cast<unsigned>(c) * planeBytes);
+                }
+            if constexpr (MODE != MODE_RHS) {
+#pragma unroll
+                for (int t = 0; t < KV; ++t) old4[t] = bld_f64(rold, row_voffset<Np, KV>(t, q, v8), f3 + static_cast<unsigned>(4 * t) * ld8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const int m = 4 * t + static_cast<int>(q);
+                if (m < Np) sOps[sBase + (3 * Np + m) * 16] = qT[t];
+            }
+            __builtin_amdgcn_wave_barrier();
+            mfma_acc_t a4[MT];
+#pragma unroll
+            for (int r = 0; r < MT; ++r) a4[r] = mfma_zero();
+            // volume term: the lane's own nodes m = 4 t + q, all four fields back from the LDS tile
+#pragma unroll
+            for (int t = 0; t < KV; ++t) {
+                const int m = 4 * t + static_cast<int>(q);
+                const bool pad = m >= Np;
+                const int ms = pad ? 0 : m;
+                const double h = pad ? 1.0 : sOps[sBase + ms * 16], hu = sOps[sBase + (Np + ms) * 16], hv = sOps[sBase + (2 * Np + ms) * 16];
+                const double hn = sOps[sBase + (3 * Np + ms) * 16];
+                const double r = fast_rcp(h);
+                const double F4 = hn * (hu * r), G4 = hn * (hv * r);
+                const double w = pad ? 0.0 : -1.0;
+                const double a = w * (geo[0] * F4 + geo[2] * G4), b = w * (geo[1] * F4 + geo[3] * G4);
+#pragma unroll
+                for (int r2 = 0; r2 < MT; ++r2) {
+                    const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
+                    const double Ads = sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane];
+                    a4[r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a, a4[r2], 0, 0, 0);
+                    a4[r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b, a4[r2], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // surface term: the same traces, wall states and face speeds as phase one
+            double s4[3][KF];
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const double nxf = geo[4 + f], nyf = geo[7 + f];
+                double e4[KF], d4[KF], lam4 = 0.0;
+#pragma unroll
+                for (int tf = 0; tf < KF; ++tf) {
+                    const int n = 4 * tf + static_cast<int>(q);
+                    e4[tf] = d4[tf] = 0.0;
+                    if (n < Nfp) {
+                        const int m = fmask_rt<N>(f, n);
+                        const double hM = sOps[sBase + m * 16], huM = sOps[sBase + (Np + m) * 16], hvM = sOps[sBase + (2 * Np + m) * 16];
+                        const double nM = sOps[sBase + (3 * Np + m) * 16];
+                        const double hq = tq[0][f][tf], nP = tq[3][f][tf];
+                        double huq = tq[1][f][tf], hvq = tq[2][f][tf];
+                        if (fidx[f][tf] < 0) { // reflective wall: no normal flow
+                            const double un = huM * nxf + hvM * nyf;
+                            huq = huM - 2 * nxf * un;
+                            hvq = hvM - 2 * nyf * un;
+                        }
+                        const double rM = fast_rcp(hM), rP = fast_rcp(hq);
+                        const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
+                        const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
+                        const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
+                        lam4 = fmax(lam4, fmax(spdM, spdP));
+                        d4[tf] = nM - nP;
+                        e4[tf] = (nM * uM - nP * uP) * nxf + (nM * vM - nP * vP) * nyf;
+                    }
+                }
+                lam4 = fmax(lam4, __shfl_xor(lam4, 16));
+                lam4 = fmax(lam4, __shfl_xor(lam4, 32));
+                const double hfs = 0.5 * geo[10 + f];
+#pragma unroll
+                for (int tf = 0; tf < KF; ++tf) s4[f][tf] = hfs * (e4[tf] - lam4 * d4[tf]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < MT; ++r) {
+#pragma unroll
+                for (int f = 0; f < 3; ++f)
+#pragma unroll
+                    for (int tf = 0; tf < KF; ++tf) {
+                        const double Al = sOps[O::OFF_LIFT + ((r * 3 + f) * KF + tf) * 64 + lane];
+                        a4[r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Al, s4[f][tf], a4[r], 0, 0, 0);
+                    }
+                if (live) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int t = 4 * r + e;
+                        if (t >= KV) continue;
+                        const int m = 4 * t + static_cast<int>(q);
+                        const double own = m < Np ? sOps[sBase + (3 * Np + m) * 16] : 0.0;
+                        const unsigned vo = row_voffset<Np, KV>(t, q, v8), soff = f3 + static_cast<unsigned>(4 * t) * ld8;
+                        const double R = a4[r][e];
+                        if constexpr (MODE == MODE_RHS) {
+                            bst_f64(rout, vo, soff, R);
+                        } else if constexpr (MODE == MODE_LSERK) {
+                            const double n1 = p.ca * old4[t] + p.cc * R;
+                            bst_f64(rold, vo, soff, n1);
+                            bst_f64(rout, vo, soff, own + p.cb * n1);
+                        } else {
+                            bst_f64(rout, vo, soff, p.ca * old4[t] + p.cb * own + p.cc * R);
+                        }
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 

@@ -65,7 +65,11 @@ struct MfmaOps {
 
 // HALO (with MODE_LSERK, partition-boundary launches): pack and unpack of the ghost exchange folded in, see
 // StageParams::haloRecv.
-template <int N, int MODE, bool HALO = false>
+// SYNC (partitioned stages, StageParams::syncWait ...): an interior launch's tiles from syncFirstTile on -- the ring of
+// elements next to the partition boundary -- wait for the previous stage's boundary launch before they read or write anything
+// and signal when their stores are visible; a boundary launch (HALO) waits for the previous interior launch's ring tiles at
+// its top and signals once per workgroup at its end.
+template <int N, int MODE, bool HALO = false, bool SYNC = false>
 __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(const StageParams p) {
     using E = Elem<N>;
     using O = MfmaOps<N>;
@@ -90,7 +94,14 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
     const double g = p.g, halfg = 0.5 * p.g;
     const unsigned kLast = static_cast<unsigned>(p.kend) - 1u;
 
+    bool synced = false;
     for (unsigned tile = wave * perWave; tile < tileEnd; ++tile) {
+        if constexpr (SYNC) {
+            if (!synced && tile >= static_cast<unsigned>(p.syncFirstTile)) {
+                sync_wait(p.syncWait, p.syncWaitValue, p.syncError);
+                synced = true;
+            }
+        }
         const unsigned kTrue = static_cast<unsigned>(p.kbegin) + tile * 16u + j;
         const bool live = kTrue <= kLast;
         const unsigned k = live ? kTrue : kLast; // padding lanes recompute the last element, store nothing
@@ -270,7 +281,11 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
                 }
             }
         }
+        if constexpr (SYNC && !HALO) {
+            if (tile >= static_cast<unsigned>(p.syncFirstTile)) sync_signal_wave(p.syncSignal);
+        }
     }
+    if constexpr (SYNC && HALO) sync_signal_workgroup(p.syncSignal);
 }
 
 } // namespace bdg_dev

@@ -45,6 +45,8 @@ constexpr bool kMfmaSources = BDG_ORDER >= 5;
 // registers, 3 spilled in the combine form and still 1.9 times the two-wave kernels); three fields at N = 8, without the
 // next-tile prefetch (registers) -- four fields' state tiles + operators + F' tiles would exceed 160 KB of LDS there
 constexpr int kMfma3SrcFields = (BDG_ORDER >= 5 && BDG_ORDER <= 7) ? 4 : (BDG_ORDER == 8 ? 3 : 0);
+// ... and at N = 8 the tracer equation as a second phase of every tile of that three-field kernel (TPHASE, sw2d_mfma3src_kernel.hpp)
+constexpr bool kTracerPhase = BDG_ORDER == 8;
 
 // Rolled kernels. FIELDS = 1 (three waves per 64 elements, one field each) exists for every
 // order; FIELDS = 3 (all fields per lane) only where 3*Np accumulators fit (N <= 6).
@@ -218,6 +220,13 @@ hipError_t launchMfma(const StageParams& p, hipStream_t stream) {
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(8, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
+    if (p.syncSignal) { // interior launch of a partitioned stage with in-kernel dependencies: one signal per ring tile
+        if constexpr (MODE == MODE_LSERK) {
+            if (p.syncSignalsOut) *p.syncSignalsOut = ntiles - std::min(ntiles, static_cast<unsigned>(p.syncFirstTile));
+            hipLaunchKernelGGL((sw2d_stage_mfma_kernel<kN, MODE_LSERK, false, true>), dim3(grid), dim3(256), ldsBytes, stream, p);
+            return hipGetLastError();
+        } else return hipErrorNotSupported;
+    }
     hipLaunchKernelGGL((sw2d_stage_mfma_kernel<kN, MODE>), dim3(grid), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }
@@ -229,6 +238,11 @@ hipError_t stageMfmaHalo(const StageParams& p, hipStream_t stream) {
     const unsigned ntiles = static_cast<unsigned>((p.kend - p.kbegin + 15) / 16);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(8, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
+    if (p.syncSignal) { // waits for the previous interior launch's ring tiles in the kernel, one signal per workgroup
+        if (p.syncSignalsOut) *p.syncSignalsOut = grid;
+        hipLaunchKernelGGL((sw2d_stage_mfma_kernel<kN, MODE_LSERK, true, true>), dim3(grid), dim3(256), ldsBytes, stream, p);
+        return hipGetLastError();
+    }
     BDG_LAUNCH_EV((sw2d_stage_mfma_kernel<kN, MODE_LSERK, true>), dim3(grid), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }
@@ -306,6 +320,19 @@ hipError_t launchMfma3(const StageParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
     return hipGetLastError();
 #else
+    if (p.syncSignal) { // interior launch of a partitioned stage with in-kernel dependencies: one signal per ring tile
+        if constexpr (MODE == MODE_LSERK && !NODAL && !NFILT) {
+            auto kernSync = sw2d_stage_mfma3_kernel<kN, MODE_LSERK, false, false, false, true>;
+            if (ldsBytes > 64 * 1024) {
+                const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernSync), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                         static_cast<int>(ldsBytes));
+                if (e != hipSuccess) return e;
+            }
+            if (p.syncSignalsOut) *p.syncSignalsOut = ntiles - std::min(ntiles, static_cast<unsigned>(p.syncFirstTile));
+            hipLaunchKernelGGL(kernSync, dim3(grid), dim3(256), ldsBytes, stream, pi);
+            return hipGetLastError();
+        } else return hipErrorNotSupported;
+    }
     BDG_LAUNCH_EV(kern, dim3(grid), dim3(256), ldsBytes, stream, pi);
     return hipGetLastError();
 #endif
@@ -337,9 +364,15 @@ hipError_t stageMfma3Halo(const StageParams& p, hipStream_t stream) {
     // boundary sets: the throughput form.
     if (ntiles <= 1024u && !std::getenv("BDG_SW2D_STRIP_THROUGHPUT")) {
         const size_t stripLds = sizeof(double) * MfmaOps2<kN>::DOUBLES;
+        if (p.syncSignal) { // waits for the previous interior launch's ring tiles in the kernel, one signal per workgroup
+            if (p.syncSignalsOut) *p.syncSignalsOut = ntiles;
+            hipLaunchKernelGGL((sw2d_strip_mfma3_kernel<kN, true>), dim3(ntiles), dim3(192), stripLds, stream, p);
+            return hipGetLastError();
+        }
         BDG_LAUNCH_EV((sw2d_strip_mfma3_kernel<kN>), dim3(ntiles), dim3(192), stripLds, stream, p);
         return hipGetLastError();
     }
+    if (p.syncSignal) return hipErrorNotSupported; // (the throughput form has no in-kernel dependencies: the caller keeps the events)
     BDG_LAUNCH_EV(kern, dim3(std::min((ntiles + 3u) / 4u, 256u)), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }
@@ -367,11 +400,12 @@ hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer
     const unsigned waves = tracer == 1 ? 3u : static_cast<unsigned>(BDG_MFMA2_WAVES);
     const unsigned perCu = static_cast<unsigned>(std::min<size_t>(waves, std::max<size_t>(1, (160u * 1024u) / ldsBytes)));
     const unsigned grid = std::min((ntiles + 3u) / 4u, 256u * perCu);
-    if (tracer == 4 || tracer == 5 || tracer == 6) { // state-once schedule with sources (and tracer); 6: variant B
+    if (tracer == 4 || tracer == 5 || tracer == 6 || tracer == 7) { // state-once schedule with sources (and tracer); 6: variant B; 7: tracer as a second phase
         if constexpr (kMfma3SrcFields == 0) return hipErrorNotSupported;
         else {
             if (tracer == 5 && kMfma3SrcFields < 4) return hipErrorNotSupported;
-            const long long arrayBytes = static_cast<long long>(tracer == 5 ? 4 : 3) * Elem<kN>::Np * p.ld * 8;
+            if (tracer == 7 && !kTracerPhase) return hipErrorNotSupported;
+            const long long arrayBytes = static_cast<long long>((tracer == 5 || tracer == 7) ? 4 : 3) * Elem<kN>::Np * p.ld * 8;
             if (arrayBytes > 4294967295LL) return hipErrorNotSupported; // one descriptor per array
             const unsigned grid3 = std::min((ntiles + 3u) / 4u, 256u); // one four-wave workgroup per CU
             auto launch = [&](auto kern, size_t lds) -> hipError_t {
@@ -386,6 +420,11 @@ hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer
             if (tracer == 5) {
                 if constexpr (kMfma3SrcFields >= 4)
                     return launch(sw2d_stage_mfma3src_kernel<kN, MODE, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
+                else return hipErrorNotSupported;
+            }
+            if (tracer == 7) {
+                if constexpr (kTracerPhase)
+                    return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 1, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
                 else return hipErrorNotSupported;
             }
             if (tracer == 6) return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 2>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
@@ -543,7 +582,7 @@ const KernelTable* BDG_CAT(kernel_table_order, BDG_ORDER)() {
     static const KernelTable table = {kN, Elem<kN>::Np, Elem<kN>::Nfp, kHighOrder ? 0 : Elem<kN>::LDS_DOUBLES, &stage,
                                       AffineOps<kN>::DOUBLES, &stageAffine, MfmaOps<kN>::DOUBLES, MfmaOps<kN>::MT,
                                       MfmaOps<kN>::KV, MfmaOps<kN>::KS, &stageMfma, &stageMfmaHalo, &stageMfma2Halo, MfmaOps2<kN>::DOUBLES, MfmaOps2<kN>::KF,
-                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma3Nodal, &stageMfma2Src, kMfma3SrcFields, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, VnOps<kN>::DOUBLES, &stageVn, &dt, &output,
+                                      &stageMfma2, &stageMfma3, &stageMfma3Halo, &stageMfma3Nodal, &stageMfma2Src, kMfma3SrcFields, kTracerPhase ? 1 : 0, VdOps<kN>::DOUBLES, &stageVd, &stageAffineSrc, &stageTracer, &stageVb, VnOps<kN>::DOUBLES, &stageVn, &dt, &output,
                                       &fmaskOf};
     return &table;
 }

@@ -60,7 +60,13 @@ def build_plan(EToV, Vert, EToE, epart, rank, world, bctype=None):
     nb_owner = epart[nb]
     remote = nb_owner != rank
     is_boundary = remote.any(axis=1)
-    own_order = np.concatenate([own[~is_boundary], own[is_boundary]])
+    # interior elements that touch a partition-boundary element (the "ring") come last among the interior ones: they are the only
+    # interior elements whose traces depend on the boundary launch of the previous stage, and a partitioned stage lets its
+    # interior launch start on the others while that launch may still be running
+    boundary_flag = np.zeros(epart.size, dtype=bool)
+    boundary_flag[own[is_boundary]] = True
+    is_ring = ~is_boundary & boundary_flag[nb].any(axis=1)
+    own_order = np.concatenate([own[~is_boundary & ~is_ring], own[is_ring], own[is_boundary]])
     num_interior = int((~is_boundary).sum())
     slot_of = np.full(epart.size, -1, dtype=np.int64)
     slot_of[own_order] = np.arange(own_order.size)

@@ -252,6 +252,7 @@ def test_loopback_rccl_result_is_independent_of_event_flags_and_halo_staging(ord
     difference between these runs (the ghost values are this rank's own elements: not physical, but deterministic)."""
     from blitzdg_amd.halo import NativeDistributedSw2d
     monkeypatch.setenv("BDG_SW2D_STRIP_THROUGHPUT", "1")       # N >= 5: both stagings on the same arithmetic
+    monkeypatch.setenv("BDG_SW2D_EVENT_SYNC", "1")             # (this test is about the event form; the counters: next test)
     results = {}
     for nofence in ("0", "1"):
         for halo_kernels in ("", "1"):
@@ -260,21 +261,46 @@ def test_loopback_rccl_result_is_independent_of_event_flags_and_halo_staging(ord
                 monkeypatch.setenv("BDG_SW2D_HALO_KERNELS", "1")
             else:
                 monkeypatch.delenv("BDG_SW2D_HALO_KERNELS", raising=False)
-            d = NativeDistributedSw2d.box(160, 80, order, 5, 8, device=0, loopback=True)
-            try:
-                d.set_initial_state(_fields)
-                dt = 0.25 * d.compute_dt(0.65)
-                for chunk in (3, 11, 23):
-                    d.lserk4_stages(dt, chunk)
-                d.barrier()
-                results[(nofence, halo_kernels)] = d.owned_state()[1:]
-            finally:
-                d.close()
+            results[(nofence, halo_kernels)] = _loopback_run(order)
     ref = results[("0", "")]
     assert np.isfinite(ref[0]).all() and np.abs(ref[1]).max() > 0
     for key, got in results.items():
         for a, b in zip(got, ref):
             assert np.array_equal(a, b), key
+
+
+def _loopback_run(order, shape=(160, 80), rank=5, chunks=(3, 11, 23)):
+    from blitzdg_amd.halo import NativeDistributedSw2d
+    d = NativeDistributedSw2d.box(shape[0], shape[1], order, rank, 8, device=0, loopback=True)
+    try:
+        d.set_initial_state(_fields)
+        dt = 0.25 * d.compute_dt(0.65)
+        for chunk in chunks:
+            d.lserk4_stages(dt, chunk)
+        d.barrier()
+        return d.owned_state()[1:]
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize("order,shape", [(2, (160, 80)), (4, (160, 80)), (4, (400, 200)), (5, (160, 80)), (6, (160, 80)), (8, (120, 80))])
+def test_loopback_rccl_in_kernel_dependencies_equal_the_event_form(order, shape, monkeypatch):
+    """Round 4: the two chains of an exchanged stage meet through device counters polled INSIDE the kernels (the ring of interior
+    tiles next to the partition boundary waits for the previous boundary launch, the boundary launch for the previous ring) instead
+    of through events on the queues. Through real RCCL (send-to-self, rank 5's share of an 8-way split; several calls, so that the
+    counters carry over): the final state must equal the event form's bit for bit -- the same kernels' arithmetic, only the
+    dependencies differ; a wait that is missing, or a hand-off that reads stale lines, shows as a difference. (400 x 200 cells:
+    a 20 000-element share whose interior launch fills the chip for several rounds while the boundary launches run beside it.)"""
+    monkeypatch.delenv("BDG_SW2D_STRIP_THROUGHPUT", raising=False)
+    monkeypatch.delenv("BDG_SW2D_HALO_KERNELS", raising=False)
+    monkeypatch.setenv("BDG_SW2D_EVENT_SYNC", "1")
+    ref = _loopback_run(order, shape)
+    monkeypatch.delenv("BDG_SW2D_EVENT_SYNC", raising=False)
+    for attempt in range(3):                     # (the interleaving of the two chains differs from run to run)
+        got = _loopback_run(order, shape)
+        assert np.isfinite(ref[0]).all() and np.abs(ref[1]).max() > 0
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), (order, attempt)
 
 
 # ---- the real multi-process path (one process per rank, the library's own communicator and stage loop) with a
@@ -312,7 +338,8 @@ def _native_worker(rank, world, port, env, out_dir, order=ORDER, strip="throughp
 
 
 @pytest.mark.parametrize("world,order,strip", [(2, 4, "throughput"), (3, 4, "throughput"), (4, 4, "throughput"),
-                                               (2, 7, "throughput"), (3, 6, "default"), (2, 8, "default")])
+                                               (2, 7, "throughput"), (3, 6, "default"), (2, 8, "default"),
+                                               (3, 4, "default"), (4, 3, "default"), (4, 5, "default")])
 def test_native_multi_process_path_matches_single_domain(tmp_path, world, order, strip, mock_rccl):
     """One process per rank exactly as under torchrun -- file rendezvous of the communicator id,
     bdg_sw2d_comm_init, the library's two-chain stage loop with grouped send / receive on the exchange
@@ -332,6 +359,8 @@ def test_native_multi_process_path_matches_single_domain(tmp_path, world, order,
         assert int(p["ghost"]) > 0 and int(p["interior"]) < int(p["owned"])
         for name, full in zip(("h", "hu", "hv"), ref):
             if strip == "throughput":
+                assert np.array_equal(p[name], full[:, ids]), f"{name} differs on a rank"
+            elif order <= 4:      # in-kernel dependencies (the default), matrix-core kernel on both sides: still bit for bit
                 assert np.array_equal(p[name], full[:, ids]), f"{name} differs on a rank"
             else:
                 assert np.abs(p[name] - full[:, ids]).max() <= 1e-12 * np.abs(full).max(), f"{name} differs on a rank"
