@@ -321,8 +321,8 @@ struct bdg_sw2d {
         static const int smallPinned = [] { const char* e = std::getenv("BDG_SW2D_SMALL_LAUNCH"); return e ? std::atoi(e) : -1; }();
         const int smallLaunch = (smallPinned >= 0 && p.kbegin == 0) ? smallPinned : kSmallLaunch[N];
         if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < smallLaunch) variant = 5;
-        if (p.syncSignal && !(affine && !variantB && !variantD && (variant == 5 || variant == 7)))
-            throw std::logic_error("in-kernel stage dependencies were requested for a launch that is not on a matrix-core kernel");
+        if (p.syncSignal && !(affine && !variantB && !variantD && (variant == 5 || variant == 7 || (variant == 0 && N <= 4))))
+            throw std::logic_error("in-kernel stage dependencies were requested for a launch whose kernel has no SYNC instance");
         if (!affine && (variantB || variantD)) {
             // per-node geometry tables: the general (rolled) form of variants B / C / D
             buildNodalVariantOps();
@@ -502,19 +502,20 @@ struct bdg_sw2d {
     // resident-workgroup kernels, interior launch of a partitioned run: CUs left to the boundary kernel (a strip of a few
     // hundred elements = 4..8 four-wave workgroups); N=8, 8-way rehearsal: 0.087 -> see profiles/r02_rehearsal.txt
     static constexpr int kInteriorGridCap = 244;
-    // ... and at N >= 5 the strip kernel's workgroups (one 16-element tile each, three waves; none fits beside an interior
-    // workgroup's 120 KB of LDS) need free CUs, or the strip -- which sits on the exchange chain -- runs in several rounds
-    // (N=8, 8-way rehearsal, 24 tiles on the 12 CUs the fixed cap left free: 27 us; on 24 free CUs 18 us). So the interior
-    // leaves one CU per strip tile, at most a quarter of the chip. Measured per stage in the 8-way rehearsal
-    // (profiles/r03_rehearsal.txt): N=5 0.061 -> 0.058 ms, N=6 0.058 -> 0.055, N=7 0.052 -> 0.049, N=8 0.065 -> 0.063 (there
-    // the interior pays it back: 1930 tiles on 232 workgroups are three rounds of a tile per wave instead of two). A cap
-    // that never adds an interior round was tried and is worse at N = 5, 6, 7. BDG_SW2D_INTERIOR_CAP=n pins the cap.
+    // ... and at N >= 5 the strip kernel's workgroups (one 16-element tile each, three waves; two fit a CU, none fits beside an
+    // interior workgroup's 120 KB of LDS) need free CUs, or the strip -- which sits on the exchange chain -- runs in many rounds.
+    // Round 3 left one CU per strip tile (cap 218-232). Round 4, with the chains meeting inside the kernels, swept the cap in
+    // the 8-way rehearsal (profiles/r04_rehearsal_experiments.txt; ms per stage): N=5 244: 0.0580, 250: 0.0521; N=6 244: 0.0486,
+    // 248: 0.0464, 252: 0.0584 (four free CUs: the strip's 32 tiles take four rounds); N=7 240: 0.0473, 246: 0.0401, 250: 0.0400;
+    // N=8 238: 0.0606 (1930 tiles are three rounds of a tile per wave on 952 waves, two on 968 and more), 242: 0.0546,
+    // 244: 0.0540, 246: 0.0542. The interior wants every CU it can get; the strip needs about a round's worth of slots for its
+    // tiles and RCCL's kernel a CU: eight free CUs, twelve at N = 8 (its strip tiles carry three row blocks).
+    // BDG_SW2D_INTERIOR_CAP=n pins the cap.
     int interiorGridCap() const {
         static const int pinned = [] { const char* e = std::getenv("BDG_SW2D_INTERIOR_CAP"); return e ? std::atoi(e) : 0; }();
         if (pinned > 0) return pinned;
         if (N < 5) return kInteriorGridCap;
-        const int stripTiles = (numOwned - numInterior + 15) / 16;
-        return std::max(192, std::min(kInteriorGridCap, 256 - stripTiles));
+        return N >= 8 ? 244 : 248;
     }
 
     void launchRhs(const double* qin, double* out, bool filter) {
@@ -649,8 +650,7 @@ struct bdg_sw2d {
         if ((eventsPinned && eventsPinned[0] != '0') || !syncBuf.p || !halosFold()) return false;
         if (std::getenv("BDG_SW2D_STRIP_THROUGHPUT") || std::getenv("BDG_SW2D_HALO_VARIANT")) return false;
         if (N >= 5) return affineVariant == 7 && (numOwned - numInterior + 15) / 16 <= 1024;
-        static const int smallPinned = [] { const char* e = std::getenv("BDG_SW2D_SMALL_LAUNCH"); return e ? std::atoi(e) : -1; }();
-        return numInterior > 0 && numInterior < (smallPinned >= 0 ? smallPinned : kSmallLaunch[N]);
+        return numInterior > 0 && affineVariant == 0; // the interior on the matrix-core kernel (small shares) or the unrolled one: both have a SYNC instance
     }
     // a bounded in-kernel wait that gave up (sync_wait) left a mark: report it the next time the host looks at the device
     void checkSyncError() {

@@ -125,24 +125,25 @@ __device__ __forceinline__ void sync_wait(const unsigned long long* ctr, unsigne
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
-// Producer, one wave for its own stores: drain them, write back this XCD's dirty L2 lines (agent-scope release), drain again
-// (the compiler may drop the wait behind the write-back when it thinks the scoreboard is empty: inline asm is invisible to that
-// pass), then one lane adds to the counter.
+// Producer: every byte that is handed off is stored WRITE-THROUGH (sc1: st_row_wt / bst_f64_wt below, the guide's R1) -- such a
+// store leaves the XCD's L2 for memory by itself, so no write-back of the whole L2 is needed before the signal. (First form of
+// this round: plain stores + an agent-scope release fence per signal, i.e. buffer_wbl2 of an L2 that the interior launch keeps
+// filling with dirty lines. 8-way rehearsal, per stage: N=4 0.0589 ms against 0.0567 with events, N=6 0.0552 against 0.0515 --
+// the write-backs cost more than the queue waits they replaced. profiles/r04_rehearsal_experiments.txt.)
+// One wave for its own stores: drain them (a store counts until it is acknowledged), then one lane adds to the counter.
 __device__ __forceinline__ void sync_signal_wave(unsigned long long* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Producer, one workgroup for all its waves' stores (every wave calls this at the end of the kernel).
+// One workgroup for all its waves' stores (every wave calls this at the end of the kernel).
 __device__ __forceinline__ void sync_signal_workgroup(unsigned long long* ctr) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0u) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0u) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// write-through store at a wave-uniform row pointer plus a per-lane byte offset (global_store_dwordx2 ... sc1)
+__device__ __forceinline__ void st_row_wt(double* row, unsigned byteOff, double v) {
+    __hip_atomic_store(reinterpret_cast<double*>(reinterpret_cast<char*>(row) + byteOff), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Sponge-layer relaxation of the reference's variant-B driver (src/sw2d/main.cpp:223-224,234-235):

@@ -50,6 +50,11 @@ __device__ __forceinline__ int bld_i32(__amdgpu_buffer_rsrc_t r, unsigned voff, 
 __device__ __forceinline__ void bst_f64(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bdg_u32x2, v), r, voff, soff, 0);
 }
+// write-through (sc1 = cache-policy bit 4: buffer_store_dwordx2 ... sc1): the store leaves the XCD's L2 for memory by itself --
+// what a tile that hands its result to a concurrently running kernel uses (sync_signal_wave, sw2d_kernels.hpp)
+__device__ __forceinline__ void bst_f64_wt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(bdg_u32x2, v), r, voff, soff, 16);
+}
 
 // Zero accumulator the compiler cannot see through. With a literal 0 as the C operand of the first matrix instruction of
 // a chain, hipcc is free to allocate a fresh destination for it, and under register pressure it has picked one that
@@ -517,7 +522,12 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3_kernel(const StagePar
                         const double n1 = p.ca * oldv[c][t] + p.cc * R;
                         const double qn = own[c][e] + p.cb * n1;
                         bst_f64(rres[c], row_voffset<Np, KV>(t, q, v8), soff, n1);
-                        bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, qn);
+                        if constexpr (SYNC) { // a ring tile hands its new state to the boundary launch: write-through
+                            if (tile >= static_cast<unsigned>(p.syncFirstTile)) bst_f64_wt(rout[c], row_voffset<Np, KV>(t, q, v8), soff, qn);
+                            else bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, qn);
+                        } else {
+                            bst_f64(rout[c], row_voffset<Np, KV>(t, q, v8), soff, qn);
+                        }
                         if constexpr (HALO) {
                             if (m < Np) {
 #pragma unroll
@@ -835,7 +845,8 @@ __global__ __launch_bounds__(192, 2) void sw2d_strip_mfma3_kernel(const StagePar
                 const double n1 = p.ca * oldv[t] + p.cc * acc[t >> 2][t & 3];
                 const double qn = own + p.cb * n1;
                 bst_f64(rres, row_voffset<Np, KV>(t, q, v8), soff, n1);
-                bst_f64(rout, row_voffset<Np, KV>(t, q, v8), soff, qn);
+                if constexpr (SYNC) bst_f64_wt(rout, row_voffset<Np, KV>(t, q, v8), soff, qn); // read by the interior launch's ring tiles
+                else bst_f64(rout, row_voffset<Np, KV>(t, q, v8), soff, qn);
                 if (m < Np) {
 #pragma unroll
                     for (int sr = 0; sr < 3; ++sr)

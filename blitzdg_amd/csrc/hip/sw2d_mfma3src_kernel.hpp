@@ -55,6 +55,10 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
     // N = 8: nothing of the next tile is requested ahead (it would not fit the registers, and a spilled register's reload
     // drains the memory pipeline); the tile's own data is requested at its top: one exposed round trip per tile
     constexpr bool PF = KV < 12;
+    // TPHASE: the tracer phase holds fewer registers than phase one, so the NEXT tile's indices, state rows and geometry are
+    // requested during it (a state row per k-step of its volume term); its source rows and neighbour traces -- L2 hits, the
+    // indices being there -- follow at the top of the tile. (Requesting those ahead as well: 114-174 spilled registers.)
+    constexpr bool PF2 = TPHASE && !PF;
 
     extern __shared__ double sOps[];
     stage_image<IMAGE, 256>(sOps, p.opsAffine);
@@ -107,6 +111,17 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         src[1][t] = bld_f64(rsy, vo, so);
         src[2][t] = bld_f64(rfc, vo, so);
     };
+    auto loadStateOnly = [&](unsigned kk, int t, double (&qs)[NF][KV]) {
+        const unsigned vo = row_voffset<Np, KV>(t, q, (q * static_cast<unsigned>(ld) + kk) * 8u), so = static_cast<unsigned>(4 * t) * ld8;
+#pragma unroll
+        for (int c = 0; c < NF; ++c) qs[c][t] = bld_f64(rq, vo, static_cast<unsigned>(c) * planeBytes + so);
+    };
+    auto loadSourceRow = [&](unsigned kk, int t, double (&src)[3][KV]) {
+        const unsigned vo = row_voffset<Np, KV>(t, q, (q * static_cast<unsigned>(ld) + kk) * 8u), so = static_cast<unsigned>(4 * t) * ld8;
+        src[0][t] = bld_f64(rsx, vo, so);
+        src[1][t] = bld_f64(rsy, vo, so);
+        src[2][t] = bld_f64(rfc, vo, so);
+    };
     auto loadIndices = [&](unsigned kk, int (&ix)[3][KF]) {
         const unsigned v4 = (q * static_cast<unsigned>(ld) + kk) * 4u;
 #pragma unroll
@@ -151,6 +166,12 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         if constexpr (PHYS == 2) btags = bld_i32(robc, kk * 4u, 0u);
     };
     if constexpr (PF) loadTile(k); // the first tile; the following ones are requested piece by piece a tile ahead
+    if constexpr (PF2) {           // ... or their indices, state rows and geometry only (TPHASE)
+        loadIndices(k, fidx);
+#pragma unroll
+        for (int t = 0; t < KV; ++t) loadStateOnly(k, t, qB);
+        loadGeometry(k, geo);
+    }
 
 #pragma unroll 1
     for (;;) {
@@ -161,7 +182,13 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         double qN[NF][KV], srcN[3][KV], geoN[13], trN[NF][3][KF], depN[2][3][KF];
         int btagsN = 0;
         int fidxN[3][KF];
-        if constexpr (!PF) loadTile(k);
+        if constexpr (!PF && !PF2) loadTile(k);
+        if constexpr (PF2) { // no branch around any of these requests (a join of control flow costs the prefetches their overlap)
+#pragma unroll
+            for (int t = 0; t < KV; ++t) loadSourceRow(k, t, srcB);
+#pragma unroll
+            for (int f = 0; f < 3; ++f) loadTraces(f, k, fidx, trP, depP);
+        }
 
         // ---- own state into the wave's LDS tile (face traces and the update read it back from there)
 #pragma unroll
@@ -354,6 +381,13 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                 }
         };
 
+        // (TPHASE) the tracer's own rows, requested here so that they are there when the second phase starts
+        double qT[TPHASE ? KV : 1];
+        if constexpr (TPHASE) {
+#pragma unroll
+            for (int t = 0; t < KV; ++t) qT[t] = bld_f64(rq, row_voffset<Np, KV>(t, q, v8), 3u * planeBytes + static_cast<unsigned>(4 * t) * ld8);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- surface term: matrix instructions only, one block of 16 output rows at a time, then that block's update
 #pragma unroll
         for (int r = 0; r < MT; ++r) {
@@ -374,9 +408,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         //      swhelpers/flux.py:17-19, rhs.py:253-258) from the state tile that is still in LDS
         if constexpr (TPHASE) {
             const unsigned f3 = 3u * planeBytes;
-            double qT[KV], old4[KV], tq[4][3][KF];
-#pragma unroll
-            for (int t = 0; t < KV; ++t) qT[t] = bld_f64(rq, row_voffset<Np, KV>(t, q, v8), f3 + static_cast<unsigned>(4 * t) * ld8);
+            double old4[KV], tq[4][3][KF];
 #pragma unroll
             for (int f = 0; f < 3; ++f)
 #pragma unroll
@@ -401,9 +433,14 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
             mfma_acc_t a4[MT];
 #pragma unroll
             for (int r = 0; r < MT; ++r) a4[r] = mfma_zero();
+            if constexpr (PF2) { // (kN = k on a wave's last tile: a harmless repeat instead of a branch)
+                loadIndices(kN, fidxN);
+                loadGeometry(kN, geoN);
+            }
             // volume term: the lane's own nodes m = 4 t + q, all four fields back from the LDS tile
 #pragma unroll
             for (int t = 0; t < KV; ++t) {
+                if constexpr (PF2) loadStateOnly(kN, t, qN);
                 const int m = 4 * t + static_cast<int>(q);
                 const bool pad = m >= Np;
                 const int ms = pad ? 0 : m;
@@ -496,7 +533,20 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         tile += tileStep;
         k = kN;
         live = liveN;
-        if constexpr (!PF) continue;
+        if constexpr (!PF && !PF2) continue;
+        if constexpr (PF2) {
+#pragma unroll
+            for (int t = 0; t < KV; ++t)
+#pragma unroll
+                for (int c = 0; c < NF; ++c) qB[c][t] = qN[c][t];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) geo[i] = geoN[i];
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int tf = 0; tf < KF; ++tf) fidx[f][tf] = fidxN[f][tf];
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < KV; ++t) {
 #pragma unroll

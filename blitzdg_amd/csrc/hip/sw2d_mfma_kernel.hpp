@@ -265,7 +265,12 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
                                 const double n1 = p.ca * oldv[reg] + p.cc * R;
                                 const double qn = qv[reg] + p.cb * n1;
                                 st_row(p.res + fo + i * ld, k8, n1);
-                                st_row(p.qout + fo + i * ld, k8, qn);
+                                if constexpr (SYNC) { // a tile that signals hands its new state to the other chain: write-through
+                                    if (HALO || tile >= static_cast<unsigned>(p.syncFirstTile)) st_row_wt(p.qout + fo + i * ld, k8, qn);
+                                    else st_row(p.qout + fo + i * ld, k8, qn);
+                                } else {
+                                    st_row(p.qout + fo + i * ld, k8, qn);
+                                }
                                 if constexpr (HALO) {
 #pragma unroll
                                     for (int sr = 0; sr < 3; ++sr)

@@ -105,6 +105,14 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
             return hipGetLastError();
         }
     }
+    if (p.syncSignal) { // interior launch of a partitioned stage with in-kernel dependencies: one signal per ring wave (64 elements)
+        if constexpr (MODE == MODE_LSERK) {
+            const unsigned firstWave = (static_cast<unsigned>(p.syncFirstTile) * 16u - static_cast<unsigned>(p.kbegin)) / kUnrolledBlock;
+            if (p.syncSignalsOut) *p.syncSignalsOut = grid - std::min(grid, firstWave);
+            hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE_LSERK, 0, false, false, true>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
+            return hipGetLastError();
+        } else return hipErrorNotSupported;
+    }
     BDG_LAUNCH_EV((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
     return hipGetLastError();
     }
