@@ -35,6 +35,8 @@ Writes
                             the same function over a continuous, non-flat bed (zx = -Hx, zy = -Hy) on a state with
                             v = 0 and |u| + sqrt(g h) uniform, without and with drag: variant B's star states,
                             bed-slope source and RHS2 drag must reproduce it
+  sw2d_bigcurved_<case>.npz the same function at g = 9.81 on a 2080-element deformed mesh (compact: coordinates, fields, outputs; the
+                            contexts are rebuilt by the test)
   curved_helpers_<case>.npz the reference's correctBCTable / makeMapsPeriodic (swhelpers/maps.py:3-65) and adjustStraightEdges /
                             deformAndBlendElements (meshhelpers/curved.py:5-136) on a channel with a headland, inputs and outputs
   advec1d_rhs_N4_K100.npz   advec1dComputeRHS(u, c, nodes1d) of the reference SCRIPT advec1d.py:12-39
@@ -349,6 +351,49 @@ def curved_case(name, mesh, order, deform, flag="deformed", periodic_x=False, g=
           f"curved={len(curvedEls)}/{len(moved)} moved |rhs|max={max(abs(a).max() for a in r):.6g}")
 
 
+def curved_big_case(name="box40x26_g981_N4", order=4, nx=40, ny=26, seed=11, g=9.81):
+    """The curved RHS at production scale and gravity: 2080 elements, g = 9.81, depth 10..11 (pressure flux g h^2 / 2 = 490,
+    whose volume and surface integrals cancel to a few units: the conditioning under which the straight-element compression of
+    the nodal-trace kernels was seen to differ from the per-point tables by 1e-11). Output of the REFERENCE's
+    swhelpers.rhs.sw2dComputeRHS_curved on contexts built by this repository's builders. Stored compactly: the mesh recipe, the
+    deformed node coordinates, the fields and source tables, the four outputs -- the Gauss / cubature contexts are rebuilt by the
+    test with the same builders (buildGaussFaceNodes(2(N+1)), buildCubatureVolumeMesh(3(N+1)))."""
+    import blitzdg_amd.pyblitzdg as dg
+    sys.path.insert(0, REF)
+    if not hasattr(np, "float"):
+        np.float = float
+    from swhelpers.rhs import sw2dComputeRHS_curved
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(nx, ny, shuffleSeed=seed)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    ctx = nodes.dgContext()
+    x0, y0 = ctx.x, ctx.y
+    x, y = bump_deformation(x0, y0, (0.3, -1.0), 0.8, (0.02, 0.05))
+    curvedEls = np.where((np.abs(x - x0) + np.abs(y - y0)).max(axis=0) > 0)[0]
+    nodes.setCoordinates(x, y)
+    J = np.dot(ctx.Dr, x) * np.dot(ctx.Ds, y) - np.dot(ctx.Ds, x) * np.dot(ctx.Dr, y)
+    gauss = nodes.buildGaussFaceNodes(2 * (order + 1))
+    cub = nodes.buildCubatureVolumeMesh(3 * (order + 1))
+    assert cub.J.min() > 0 and gauss.J.min() > 0
+    h, hu, hv = seeded_fields(x, y)                       # depth 10 .. 11
+    rng = np.random.default_rng(3)
+    hN = h * (0.5 + 0.3 * np.sin(2 * x) * np.cos(3 * y)) + 0.02 * rng.standard_normal(x.shape)
+    H = 10.0 - 0.05 * x + 0.02 * y * y
+    zx, zy = 0.05 + 0 * x, -0.04 * y
+    f, CD = 7.8825e-5 * 1e3, 2.5e-3 * (1.0 + 0.5 * np.cos(x))
+    gmapW = np.array(gauss.BCmap.get(3, []), dtype=np.int32)
+    ref_ctx = types.SimpleNamespace(numLocalPoints=ctx.numLocalPoints, numElements=ctx.numElements, V=ctx.V)
+    ref_cub = types.SimpleNamespace(V=cub.V, Dr=cub.Dr, Ds=cub.Ds, W=cub.W, rx=cub.rx, ry=cub.ry, sx=cub.sx, sy=cub.sy, MMChol=cub.MMChol)
+    ref_gauss = types.SimpleNamespace(nx=gauss.nx, ny=gauss.ny, BCmap=gauss.BCmap, Interp=gauss.Interp, W=gauss.W)
+    r = sw2dComputeRHS_curved(h, hu, hv, hN, zx, zy, g, H, f, CD, ref_ctx, ref_cub, ref_gauss, curvedEls, J, gauss.mapM, gauss.mapP)
+    np.savez_compressed(os.path.join(HERE, f"sw2d_bigcurved_{name}.npz"), order=order, nx=nx, ny=ny, seed=seed, g=g, f=f, x=x, y=y,
+                        curvedEls=curvedEls.astype(np.int32), h=h, hu=hu, hv=hv, hN=hN, zx=zx, zy=zy, CD=CD, num_wall=gmapW.size,
+                        rhs1=r[0], rhs2=r[1], rhs3=r[2], rhs4=r[3])
+    print(f"sw2d_bigcurved_{name}.npz: K={ctx.numElements} curved={curvedEls.size} |rhs|max={max(abs(a).max() for a in r):.6g} "
+          f"file={os.path.getsize(os.path.join(HERE, f'sw2d_bigcurved_{name}.npz')) / 1e6:.2f} MB")
+
+
 def script_functions(path, names):
     """The named top-level function definitions of a reference SCRIPT (one that cannot be imported
     because its module body needs pyblitzdg and runs a whole simulation), compiled on their own with
@@ -573,6 +618,8 @@ def curved_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "curved":
         curved_cases()
+    elif len(sys.argv) > 1 and sys.argv[1] == "curved_big":
+        curved_big_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "curved_helpers":
         curved_helpers_case()
     elif len(sys.argv) > 1 and sys.argv[1] == "variant_b":

@@ -340,3 +340,34 @@ def test_advec1d_rhs_matches_the_reference_script_function():
         orc = advec1d_rhs(d["Dr"], d["Lift"], d["rx"], d["Fscale"], d["nx"], d["vmapM"], d["vmapP"], int(d["mapI"]),
                           int(d["mapO"]), float(d["c"]), u)
         assert np.abs(orc - ref).max() / scale < 1e-13
+
+
+def test_numpy_restatement_reproduces_the_reference_at_production_gravity():
+    """The curved restatement on the 2080-element, g = 9.81 fixture (tests/golden/sw2d_bigcurved_*.npz: output of the reference's
+    sw2dComputeRHS_curved; the contexts are rebuilt here from the stored coordinates with this repository's builders, as the GPU
+    test does): to round-off of the rebuilt tables (bit for bit when the builders have not changed since the fixture was made)."""
+    import glob
+    import blitzdg_amd.pyblitzdg as dg
+    from oracle import oracle_np
+    from conftest import GOLDEN
+    import os
+    paths = sorted(glob.glob(os.path.join(GOLDEN, "sw2d_bigcurved_*.npz")))
+    assert paths
+    for path in paths:
+        d = np.load(path)
+        order = int(d["order"])
+        mesh = dg.MeshManager()
+        mesh.buildBoxMesh(int(d["nx"]), int(d["ny"]), shuffleSeed=int(d["seed"]))
+        nodes = dg.TriangleNodesProvisioner(order, mesh)
+        ctx = nodes.dgContext()
+        x, y = d["x"], d["y"]
+        nodes.setCoordinates(x, y)
+        J = np.dot(ctx.Dr, x) * np.dot(ctx.Ds, y) - np.dot(ctx.Ds, x) * np.dot(ctx.Dr, y)
+        gauss, cub = nodes.buildGaussFaceNodes(2 * (order + 1)), nodes.buildCubatureVolumeMesh(3 * (order + 1))
+        t = dict(cubV=cub.V, cubDr=cub.Dr, cubDs=cub.Ds, cubW=cub.W, cubrx=cub.rx, cubry=cub.ry, cubsx=cub.sx, cubsy=cub.sy,
+                 gInterp=gauss.Interp, gW=gauss.W, gnx=gauss.nx, gny=gauss.ny, gmapM=gauss.mapM, gmapP=gauss.mapP,
+                 gmapW=np.array(gauss.BCmap[3], dtype=np.int32), V=ctx.V, J=J, MMChol=cub.MMChol, curvedEls=d["curvedEls"])
+        got = oracle_np.sw2d_rhs_curved(d["h"], d["hu"], d["hv"], d["hN"], d["zx"], d["zy"], float(d["g"]), float(d["f"]), d["CD"], t)
+        ref = [d[f"rhs{i}"] for i in (1, 2, 3, 4)]
+        scale = max(np.abs(r).max() for r in ref)
+        assert max(np.abs(a - b).max() for a, b in zip(got, ref)) <= 1e-13 * scale

@@ -502,3 +502,56 @@ def test_set_partition_refuses_a_plan_that_would_race(form):
     assert s.deviceBytes == held                                   # a replaced buffer is not counted twice
     with pytest.raises(BdgError, match="no communicator"):
         check(lib.bdg_sw2d_curved_step_rk2_exchanged(s._h, 1e-3, 1, 0))
+
+
+# ---- the curved RHS at production scale and gravity (round 4): g = 9.81, depth 10..11, 2080 elements, 553 of them curved
+
+BIG = sorted(glob.glob(os.path.join(GOLDEN, "sw2d_bigcurved_*.npz")))
+# Measured on the GPU against the reference function's stored output (printed by the test): the pressure flux
+# g h^2 / 2 = 490 enters volume and surface integrals that cancel to a few units, so every form carries eps * 490 / |RHS| more
+# round-off than at the small fixtures' g = 0.0245.
+BIG_TOL = 2e-11
+
+
+def rebuilt_contexts(d):
+    """The contexts the reference function was given when the fixture was made, from the stored coordinates with the same builders."""
+    order = int(d["order"])
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(int(d["nx"]), int(d["ny"]), shuffleSeed=int(d["seed"]))
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    nodes.buildFilter(0.9 * order, order)
+    ctx = nodes.dgContext()
+    x, y = d["x"], d["y"]
+    nodes.setCoordinates(x, y)
+    J = np.dot(ctx.Dr, x) * np.dot(ctx.Ds, y) - np.dot(ctx.Ds, x) * np.dot(ctx.Dr, y)
+    gauss = nodes.buildGaussFaceNodes(2 * (order + 1))
+    cub = nodes.buildCubatureVolumeMesh(3 * (order + 1))
+    return nodes, ctx, cub, gauss, J
+
+
+@pytest.mark.parametrize("path", BIG, ids=[os.path.basename(p)[15:-4] for p in BIG])
+def test_curved_rhs_at_production_gravity_matches_the_reference_function(path, form, monkeypatch):
+    """Both kernel forms (and the nodal-trace form with its straight-element compression switched off) against the output of the
+    reference's swhelpers.rhs.sw2dComputeRHS_curved at g = 9.81 on a 2080-element deformed mesh: the tolerance the solver is
+    documented with at production scale."""
+    d = np.load(path)
+    nodes, ctx, cub, gauss, J = rebuilt_contexts(d)
+    assert len(gauss.BCmap[3]) == int(d["num_wall"])
+    ref = [d[f"rhs{i}"] for i in (1, 2, 3, 4)]
+    errs = {}
+    for label, env in (("default", None), ("tables", "1")):
+        if env:
+            monkeypatch.setenv("BDG_SW2D_CURVED_NO_AFFINE", env)
+        else:
+            monkeypatch.delenv("BDG_SW2D_CURVED_NO_AFFINE", raising=False)
+        s = Sw2dCurvedSolver(ctx, cub, gauss, d["curvedEls"], J, gauss.mapM, gauss.mapP, g=float(d["g"]), zx=d["zx"], zy=d["zy"],
+                             f=float(d["f"]), CD=d["CD"])
+        assert s.usesNodalTraces == (form == "nodal-trace")
+        got = s.computeRHS(d["h"], d["hu"], d["hv"], d["hN"])
+        errs[label] = relerr(got, ref)
+        straight = np.setdiff1d(np.arange(J.shape[1]), d["curvedEls"])
+        scale = max(np.abs(r).max() for r in ref)
+        errs[label + " straight"] = max(np.abs(a[:, straight] - b[:, straight]).max() for a, b in zip(got, ref)) / scale
+        errs[label + " curved"] = max(np.abs(a[:, d["curvedEls"]] - b[:, d["curvedEls"]]).max() for a, b in zip(got, ref)) / scale
+    print(f"curved RHS, g = 9.81, K = {J.shape[1]}, form {form}: relative to max|RHS| " + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert max(errs.values()) < BIG_TOL, errs
