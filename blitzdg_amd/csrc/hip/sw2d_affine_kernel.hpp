@@ -95,33 +95,17 @@ struct PhysParams {
 // TRACER: the passive tracer hN (field 3; F4 = hN u, G4 = hN v, no sources) in the same pass.
 // SPONGE (MODE_COMBINE only): the momentum relaxation of the SSP-RK2 + sponge scheme is applied after the update; a
 // launch with StageParams::sponge == 0 takes the instance without it.
-// SYNC (interior launches of a partitioned LSERK stage whose share is large enough for this kernel: 2- and 4-way splits of C3;
-// one-wave workgroups): the waves from element StageParams::syncFirstTile * 16 on -- the ring next to the partition boundary,
-// ordered last -- wait for the previous stage's boundary launch before they touch anything, store their new state
-// write-through and signal (sw2d_kernels.hpp: sync_wait, st_row_wt, sync_signal_wave).
-template <int N, int MODE, int PHYS = 0, bool TRACER = false, bool SPONGE = false, bool SYNC = false>
+template <int N, int MODE, int PHYS = 0, bool TRACER = false, bool SPONGE = false>
 __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParams p, const PhysParams ph) {
     using E = Elem<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN;
-    static_assert(!SYNC || (MODE == MODE_LSERK && PHYS == 0 && !TRACER), "in-kernel stage dependencies: three-field LSERK stages");
 
     const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
     const unsigned tile = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
     // 32-bit element index: every row pointer below is wave-uniform (SGPR base) and the lane
     // part is a 32-bit offset, so a load needs no 64-bit vector address arithmetic.
     const unsigned k = static_cast<unsigned>(p.kbegin) + tile * blockDim.x + threadIdx.x;
-    // (SYNC: one-wave workgroups, so the test is wave-uniform; the whole wave waits, also its lanes beyond kend)
-    bool ringWave = false;
-    if constexpr (SYNC) {
-        ringWave = static_cast<unsigned>(p.kbegin) + (tile + 1u) * blockDim.x > static_cast<unsigned>(p.syncFirstTile) * 16u;
-        if (ringWave) sync_wait(p.syncWait, p.syncWaitValue, p.syncError);
-    }
-    if (k >= static_cast<unsigned>(p.kend)) {
-        if constexpr (SYNC) {
-            if (ringWave) sync_signal_wave(p.syncSignal); // (a partly filled last wave: its live lanes signal below)
-        }
-        return;
-    }
+    if (k >= static_cast<unsigned>(p.kend)) return;
     const unsigned k8 = k * 8u, k4 = k * 4u; // Np*ld*8 < 2^32 is checked on the host
 
     const long long ld = p.ld, plane = static_cast<long long>(Np) * ld;
@@ -393,23 +377,14 @@ __global__ __launch_bounds__(256) void sw2d_stage_affine_kernel(const StageParam
             st_row(rs + i * ld, k8, n1);
             st_row(rs + plane + i * ld, k8, n2);
             st_row(rs + 2 * plane + i * ld, k8, n3);
-            if constexpr (SYNC) { // every wave of this instance stores its new state write-through: no per-node branch in the unrolled body
-                st_row_wt(o + i * ld, k8, h[i] + b * n1);
-                st_row_wt(o + plane + i * ld, k8, hu[i] + b * n2);
-                st_row_wt(o + 2 * plane + i * ld, k8, hv[i] + b * n3);
-            } else {
-                st_row(o + i * ld, k8, h[i] + b * n1);
-                st_row(o + plane + i * ld, k8, hu[i] + b * n2);
-                st_row(o + 2 * plane + i * ld, k8, hv[i] + b * n3);
-            }
+            st_row(o + i * ld, k8, h[i] + b * n1);
+            st_row(o + plane + i * ld, k8, hu[i] + b * n2);
+            st_row(o + 2 * plane + i * ld, k8, hv[i] + b * n3);
             if constexpr (TRACER) {
                 const double n4 = a * old4[i] + dt * R4[i];
                 st_row(rs + 3 * plane + i * ld, k8, n4);
                 st_row(o + 3 * plane + i * ld, k8, hN[i] + b * n4);
             }
-        }
-        if constexpr (SYNC) {
-            if (ringWave) sync_signal_wave(p.syncSignal);
         }
     } else {
         // The sponge (a division per momentum value) is a template parameter: with the test inside sponge_relax the unrolled

@@ -321,7 +321,7 @@ struct bdg_sw2d {
         static const int smallPinned = [] { const char* e = std::getenv("BDG_SW2D_SMALL_LAUNCH"); return e ? std::atoi(e) : -1; }();
         const int smallLaunch = (smallPinned >= 0 && p.kbegin == 0) ? smallPinned : kSmallLaunch[N];
         if (!variantForced && affine && N <= 5 && p.kend - p.kbegin < smallLaunch) variant = 5;
-        if (p.syncSignal && !(affine && !variantB && !variantD && (variant == 5 || variant == 7 || (variant == 0 && N <= 4))))
+        if (p.syncSignal && !(affine && !variantB && !variantD && (variant == 5 || variant == 7)))
             throw std::logic_error("in-kernel stage dependencies were requested for a launch whose kernel has no SYNC instance");
         if (!affine && (variantB || variantD)) {
             // per-node geometry tables: the general (rolled) form of variants B / C / D
@@ -650,7 +650,12 @@ struct bdg_sw2d {
         if ((eventsPinned && eventsPinned[0] != '0') || !syncBuf.p || !halosFold()) return false;
         if (std::getenv("BDG_SW2D_STRIP_THROUGHPUT") || std::getenv("BDG_SW2D_HALO_VARIANT")) return false;
         if (N >= 5) return affineVariant == 7 && (numOwned - numInterior + 15) / 16 <= 1024;
-        return numInterior > 0 && affineVariant == 0; // the interior on the matrix-core kernel (small shares) or the unrolled one: both have a SYNC instance
+        // N <= 4: only while the interior share is small enough for the matrix-core kernel (8-way split of C3). A SYNC instance of
+        // the unrolled kernel (the wait in front of its one big basic block, ring waves storing write-through) was built and
+        // measured in the 2- and 4-way rehearsal: 0.332 / 0.164 ms per stage against 0.220 / 0.121 with the events -- the branch
+        // at the top costs that kernel its load batching (profiles/r04_rehearsal_experiments.txt); larger shares keep the events.
+        static const int smallPinned = [] { const char* e = std::getenv("BDG_SW2D_SMALL_LAUNCH"); return e ? std::atoi(e) : -1; }();
+        return numInterior > 0 && affineVariant == 0 && numInterior < (smallPinned >= 0 ? smallPinned : kSmallLaunch[N]);
     }
     // a bounded in-kernel wait that gave up (sync_wait) left a mark: report it the next time the host looks at the device
     void checkSyncError() {
@@ -1198,7 +1203,7 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->affineVariant = s->N <= 4 ? 0 : 7;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 7) {
+        if (v >= 0 && v <= 8) {
             s->affineVariant = v;
             s->variantForced = true;
         }

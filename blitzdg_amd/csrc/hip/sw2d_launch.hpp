@@ -3,6 +3,7 @@
 // kernels build in parallel; the solver picks the table at run time.
 #pragma once
 #include "sw2d_affine_kernel.hpp"
+#include "sw2d_affine_lean_kernel.hpp"
 #include "sw2d_vd_kernel.hpp"
 #include "sw2d_tracer_kernel.hpp"
 #include "sw2d_vb_kernel.hpp"

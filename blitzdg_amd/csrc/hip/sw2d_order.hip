@@ -105,14 +105,7 @@ hipError_t launchAffine(const StageParams& p, hipStream_t stream) {
             return hipGetLastError();
         }
     }
-    if (p.syncSignal) { // interior launch of a partitioned stage with in-kernel dependencies: one signal per ring wave (64 elements)
-        if constexpr (MODE == MODE_LSERK) {
-            const unsigned firstWave = (static_cast<unsigned>(p.syncFirstTile) * 16u - static_cast<unsigned>(p.kbegin)) / kUnrolledBlock;
-            if (p.syncSignalsOut) *p.syncSignalsOut = grid - std::min(grid, firstWave);
-            hipLaunchKernelGGL((sw2d_stage_affine_kernel<kN, MODE_LSERK, 0, false, false, true>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
-            return hipGetLastError();
-        } else return hipErrorNotSupported;
-    }
+    if (p.syncSignal) return hipErrorNotSupported; // (no SYNC instance of the unrolled kernel: see flagSyncUsable in sw2d_device.hip)
     BDG_LAUNCH_EV((sw2d_stage_affine_kernel<kN, MODE>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, PhysParams{});
     return hipGetLastError();
     }
@@ -193,6 +186,17 @@ hipError_t launchStream(const StageParams& p, hipStream_t stream) {
 // variant: 0 = register-resident state (1 wave/SIMD), 2 / 3 = streamed state at 2 / 3 waves per SIMD
 hipError_t stageAffine(int mode, int variant, const StageParams& p, hipStream_t stream) {
     if (variant == 1) return stageFieldSplit(mode, p, stream);
+    if (variant == 8) { // A/B: state-resident kernel at two waves per SIMD (sw2d_affine_lean_kernel.hpp), LSERK stages; other modes: variant 0
+        if constexpr (!kNoStream) {
+            if (mode == MODE_LSERK) {
+                if (p.kend <= p.kbegin) return hipSuccess;
+                const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kUnrolledBlock - 1) / kUnrolledBlock);
+                hipLaunchKernelGGL((sw2d_stage_affine_lean_kernel<kN>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p);
+                return hipGetLastError();
+            }
+        }
+        variant = 0;
+    }
     if (variant == 4) {
         if constexpr (kHighOrder) return stageFieldSplit(mode, p, stream);
         else return stageRolled<3>(mode, p, stream);
