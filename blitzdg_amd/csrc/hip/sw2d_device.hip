@@ -1203,7 +1203,7 @@ bdg_sw2d* createSolver(const bdg_sw2d_desc& d) {
     s->affineVariant = s->N <= 4 ? 0 : 7;
     if (const char* e = std::getenv("BDG_SW2D_AFFINE_VARIANT")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 8) {
+        if (v >= 0 && v <= 9) {
             s->affineVariant = v;
             s->variantForced = true;
         }

@@ -11,6 +11,7 @@
 #include "sw2d_mfma_kernel.hpp"
 #include "sw2d_mfma3_kernel.hpp"
 #include "sw2d_mfma3src_kernel.hpp"
+#include "sw2d_affine_xchg_kernel.hpp"
 #include "sw2d_kernels.hpp"
 
 namespace bdg_dev {

@@ -243,6 +243,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         // pointwise work of the surface term, one face node per lane at a time, spread over the volume k-steps
         double sF[3][NF][KF];
         double eF[NF][KF], dF[NF][KF], lamF = 0.0;
+        double lamKeep[TPHASE ? 3 : 1]; // (TPHASE) the faces' speeds, kept for the tracer phase: 36 square roots per tile it need not redo
         auto faceNode = [&](int f, int tf) {
             const double nxf = geo[4 + f], nyf = geo[7 + f];
             const int n = 4 * tf + static_cast<int>(q);
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                     lam = fmax(lam, __shfl_xor(lam, 32));
                 }
                 const double hfs = 0.5 * geo[10 + f];
+                if constexpr (TPHASE) lamKeep[f] = lam;
 #pragma unroll
                 for (int t2 = 0; t2 < KF; ++t2)
 #pragma unroll
@@ -459,12 +461,13 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            // surface term: the same traces, wall states and face speeds as phase one
+            // surface term: the same traces and wall states as phase one, its face speeds (lamKeep)
             double s4[3][KF];
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
                 const double nxf = geo[4 + f], nyf = geo[7 + f];
-                double e4[KF], d4[KF], lam4 = 0.0;
+                double e4[KF], d4[KF];
+                const double lam4 = lamKeep[f];
 #pragma unroll
                 for (int tf = 0; tf < KF; ++tf) {
                     const int n = 4 * tf + static_cast<int>(q);
@@ -482,15 +485,10 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
                         }
                         const double rM = fast_rcp(hM), rP = fast_rcp(hq);
                         const double uM = huM * rM, vM = hvM * rM, uP = huq * rP, vP = hvq * rP;
-                        const double spdM = fast_sqrt(uM * uM + vM * vM) + fast_sqrt(g * hM);
-                        const double spdP = fast_sqrt(uP * uP + vP * vP) + fast_sqrt(g * hq);
-                        lam4 = fmax(lam4, fmax(spdM, spdP));
                         d4[tf] = nM - nP;
                         e4[tf] = (nM * uM - nP * uP) * nxf + (nM * vM - nP * vP) * nyf;
                     }
                 }
-                lam4 = fmax(lam4, __shfl_xor(lam4, 16));
-                lam4 = fmax(lam4, __shfl_xor(lam4, 32));
                 const double hfs = 0.5 * geo[10 + f];
 #pragma unroll
                 for (int tf = 0; tf < KF; ++tf) s4[f][tf] = hfs * (e4[tf] - lam4 * d4[tf]);

@@ -186,6 +186,18 @@ hipError_t launchStream(const StageParams& p, hipStream_t stream) {
 // variant: 0 = register-resident state (1 wave/SIMD), 2 / 3 = streamed state at 2 / 3 waves per SIMD
 hipError_t stageAffine(int mode, int variant, const StageParams& p, hipStream_t stream) {
     if (variant == 1) return stageFieldSplit(mode, p, stream);
+    if (variant == 9) { // A/B: in-wave neighbour traces through LDS (sw2d_affine_xchg_kernel.hpp), LSERK stages; other modes: variant 0
+        if constexpr (!kNoStream) {
+            if (mode == MODE_LSERK && 3ll * Elem<kN>::Np * p.ld * 8 <= 4294967295ll) {
+                if (p.kend <= p.kbegin) return hipSuccess;
+                const unsigned grid = static_cast<unsigned>((p.kend - p.kbegin + kUnrolledBlock - 1) / kUnrolledBlock);
+                const unsigned magic = static_cast<unsigned>((0x100000000ull + static_cast<unsigned long long>(p.ld) - 1ull) / static_cast<unsigned long long>(p.ld));
+                hipLaunchKernelGGL((sw2d_stage_affine_xchg_kernel<kN>), dim3(grid), dim3(kUnrolledBlock), 0, stream, p, magic);
+                return hipGetLastError();
+            }
+        }
+        variant = 0;
+    }
     if (variant == 8) { // A/B: state-resident kernel at two waves per SIMD (sw2d_affine_lean_kernel.hpp), LSERK stages; other modes: variant 0
         if constexpr (!kNoStream) {
             if (mode == MODE_LSERK) {

@@ -366,17 +366,14 @@ __global__ __launch_bounds__(256) void sw2d_stage_vb_unrolled_kernel(const Stage
 #pragma unroll
         for (int n = 0; n < Nfp; ++n) {
             const int j = f * Nfp + n, m = E::fmask(f, n);
-            double hq = hP[j], huq = huP[j], hvq = hvP[j];
-            if ((tags >> j) & 1) {         // open boundary: surface follows the tide (:348-353)
-                huq = hu[m];
-                hvq = hv[m];
-                hq = HM[j] + vp.tide;
-            } else if (idx[j] < 0) {       // reflective wall (:340-345)
-                const double un = hu[m] * nxf + hv[m] * nyf;
-                hq = h[m];
-                huq = hu[m] - 2 * nxf * un;
-                hvq = hv[m] - 2 * nyf * un;
-            }
+            // open boundary: the surface follows the tide (:348-353); reflective wall (:340-345); else the neighbour's trace -- by
+            // SELECTS: as an if / else-if per face node these were fifteen branches in the unrolled body (the scheduler lost its one
+            // region: 398 scalar registers spilled to vector lanes, 22 branches in the RHS instance against 3 in variant A's kernel)
+            const bool open = ((tags >> j) & 1) != 0, wall = (idx[j] < 0) & !open;
+            const double un = hu[m] * nxf + hv[m] * nyf;
+            const double hq = open ? HM[j] + vp.tide : (wall ? h[m] : hP[j]);
+            const double huq = open ? hu[m] : (wall ? hu[m] - 2 * nxf * un : huP[j]);
+            const double hvq = open ? hv[m] : (wall ? hv[m] - 2 * nyf * un : hvP[j]);
             const double bM = -HM[j], bP = -HP[j], mx = fmax(bP, bM);
             const double hMs = fmax(0.0, h[m] + bM - mx), hPs = fmax(0.0, hq + bP - mx);
             const double rM = fast_rcp(hMs), rP = fast_rcp(hPs);
@@ -505,14 +502,18 @@ __global__ __launch_bounds__(256) void sw2d_stage_vb_unrolled_kernel(const Stage
         }
     }
 
-    // ---- global speed of the next evaluation from the state just written (h, hu, hv now hold it)
+    // ---- global speed of the next evaluation from the state just written (h, hu, hv now hold it). Round 4: the '-' star
+    //      states of all face nodes in one branch-free loop (an interior '+' star state is the neighbour's '-' star state, which that
+    //      element's lane covers), then ONE branch for the lanes that have a boundary node at all -- the rebuilt '+' states of
+    //      open-boundary and wall nodes, by selects inside. Round 3 tested every node (fifteen divergent branches with IEEE
+    //      square roots behind them in the unrolled body): 395-813 spilled scalar registers, 0.509 ms per LSERK4 stage at C3.
+    //      The arithmetic (IEEE sqrt, contraction as the speed pass has it) is unchanged: the value equals sw2d_vb_speed_kernel's.
     if constexpr (MODE != MODE_RHS) {
         if (vp.lamNext) {
             double best = 0.0;
-            bool bad = false;
+            bool anyBoundary = tags != 0;
 #pragma unroll
             for (int f = 0; f < 3; ++f) {
-                const double nxf = fnx[f], nyf = fny[f];
 #pragma unroll
                 for (int n = 0; n < Nfp; ++n) {
                     const int j = f * Nfp + n, m = E::fmask(f, n);
@@ -523,29 +524,36 @@ __global__ __launch_bounds__(256) void sw2d_stage_vb_unrolled_kernel(const Stage
                     const double rM = fast_rcp(hMs);
                     const double huMs = hMs * (hu[m] * rM), hvMs = hMs * (hv[m] * rM);
                     const double uM = huMs * rM, vM = hvMs * rM;
-                    double spd = sqrt(uM * uM + vM * vM) + sqrt(g * hMs);
-                    const bool open = (tags >> j) & 1;
-                    if (open || idx[j] < 0) { // boundary: the '+' state is built from the element's own
-                        double hq = h[m], huq = hu[m], hvq = hv[m];
-                        if (open) hq = HMj + vp.tideNext;
-                        else {
-                            const double un = hu[m] * nxf + hv[m] * nyf;
-                            huq = hu[m] - 2 * nxf * un;
-                            hvq = hv[m] - 2 * nyf * un;
-                        }
+                    const double spd = sqrt(uM * uM + vM * vM) + sqrt(g * hMs);
+                    anyBoundary = anyBoundary | (idx[j] < 0);
+                    best = ((spd != spd) | (best != best)) ? __builtin_nan("") : fmax(best, spd); // a NaN stays
+                }
+            }
+            if (anyBoundary) { // rare: elements on the domain boundary
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const double nxf = fnx[f], nyf = fny[f];
+#pragma unroll
+                    for (int n = 0; n < Nfp; ++n) {
+                        const int j = f * Nfp + n, m = E::fmask(f, n);
+                        const bool open = ((tags >> j) & 1) != 0, wall = idx[j] < 0;
+                        const double HMj = ld_row(vp.H + m * ld, k8);
+                        const double HPj = ld_row(vp.H, static_cast<unsigned>(idx[j] < 0 ? -(idx[j] + 1) : idx[j]) * 8u);
+                        const double bM = -HMj, bP = -HPj, mx = fmax(bP, bM);
+                        const double un = hu[m] * nxf + hv[m] * nyf;
+                        const double hq = open ? HMj + vp.tideNext : h[m];
+                        const double huq = open ? hu[m] : hu[m] - 2 * nxf * un;
+                        const double hvq = open ? hv[m] : hv[m] - 2 * nyf * un;
                         const double hPs = fmax(0.0, hq + bP - mx);
                         const double rP = fast_rcp(hPs);
                         const double huPs = hPs * (huq * rP), hvPs = hPs * (hvq * rP);
                         const double uP = huPs * rP, vP = hvPs * rP;
                         const double spdP = sqrt(uP * uP + vP * vP) + sqrt(g * hPs);
-                        if (spdP != spdP) bad = true;
-                        spd = fmax(spd, spdP);
+                        const bool here = open | wall;
+                        best = (here & ((spdP != spdP) | (best != best))) ? __builtin_nan("") : (here ? fmax(best, spdP) : best);
                     }
-                    if (spd != spd) bad = true;
-                    best = fmax(best, spd);
                 }
             }
-            if (bad) best = __builtin_nan("");
             unsigned long long bits = static_cast<unsigned long long>(__double_as_longlong(best));
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
