@@ -676,6 +676,33 @@ def test_cpp_driver_sw2d_tidal_matches_oracle_replay(mode, coarse_mesh):
     assert abs(hvmax - np.abs(q[2]).max()) / np.abs(q[2]).max() < 1e-8
 
 
+@pytest.mark.parametrize("variant", [8, 9])
+@pytest.mark.parametrize("order,nx,ny,seed", [(2, 37, 23, 0), (4, 41, 29, 0), (4, 41, 29, 9), (5, 19, 13, 0)])
+def test_round4_ab_variants_equal_the_unrolled_kernel_bit_for_bit(variant, order, nx, ny, seed, monkeypatch):
+    """BDG_SW2D_AFFINE_VARIANT=8 (state-resident kernel at two waves per SIMD, sw2d_affine_lean_kernel.hpp) and =9 (neighbour traces
+    of in-wave faces exchanged through LDS, sw2d_affine_xchg_kernel.hpp): the same node-by-node arithmetic as the unrolled kernel
+    (variant 0) -- 11 LSERK4 stages on a mesh of several dozen waves with a ragged last one, natural order (most neighbours inside
+    the wave) and shuffled (hardly any), must leave identical bits."""
+    m = dg.MeshManager()
+    m.buildBoxMesh(nx, ny, shuffleSeed=seed)
+    nodes = dg.TriangleNodesProvisioner(order, m)
+    ctx = nodes.dgContext()
+    x, y = ctx.x, ctx.y
+    q0 = (10.0 + np.exp(-10 * x * x - 10 * y * y), 0.3 * np.sin(3 * x + 1) * np.cos(2 * y), 0.3 * np.cos(2 * x) * np.sin(3 * y - 1))
+    out = {}
+    for v in (0, variant):
+        monkeypatch.setenv("BDG_SW2D_AFFINE_VARIANT", str(v))
+        s = sw2d.Sw2dSolver(nodes=nodes, flags=sw2d.KEEP_ORDER)
+        s.setState(*q0)
+        dt = 0.5 * s.computeDt(0.65)[0]
+        s.lserk4Stages(dt, 11)
+        out[v] = s.getState()
+        s.close()
+    assert np.abs(out[0][1] - q0[1]).max() > 1e-6
+    for a, b in zip(out[variant], out[0]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N4", "coarse_box_N6", "box2x2_N8"])
 def test_every_affine_kernel_variant_matches_the_reference_fixture(variant, case, monkeypatch):
