@@ -8,7 +8,8 @@
 // rest: neighbour traces are gathered one face at a time (requesting the next face's behind the current face's lift products
 // spilled 178 registers), velocities are formed twice per face node instead of kept, and the residual rows arrive in batches
 // of five nodes during the update -- latencies the partner wave is there to cover.
-// Same operator image (AffineOps, plain or pre-filtered), same node-by-node arithmetic as variant 0: results are bit-identical.
+// Same operator image (AffineOps, plain or pre-filtered), same node-by-node arithmetic as variant 0, but the volume term is
+// accumulated before the surface term (variant 0: after it): results equal variant 0's to round-off, not bit for bit.
 // LSERK stages only (what the benchmark times); selected with BDG_SW2D_AFFINE_VARIANT=8.
 #pragma once
 #include "sw2d_affine_kernel.hpp"

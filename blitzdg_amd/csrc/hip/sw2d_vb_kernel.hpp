@@ -369,11 +369,26 @@ __global__ __launch_bounds__(256) void sw2d_stage_vb_unrolled_kernel(const Stage
             // open boundary: the surface follows the tide (:348-353); reflective wall (:340-345); else the neighbour's trace -- by
             // SELECTS: as an if / else-if per face node these were fifteen branches in the unrolled body (the scheduler lost its one
             // region: 398 scalar registers spilled to vector lanes, 22 branches in the RHS instance against 3 in variant A's kernel)
-            const bool open = ((tags >> j) & 1) != 0, wall = (idx[j] < 0) & !open;
-            const double un = hu[m] * nxf + hv[m] * nyf;
-            const double hq = open ? HM[j] + vp.tide : (wall ? h[m] : hP[j]);
-            const double huq = open ? hu[m] : (wall ? hu[m] - 2 * nxf * un : huP[j]);
-            const double hvq = open ? hv[m] : (wall ? hv[m] - 2 * nyf * un : hvP[j]);
+            double hq = hP[j], huq = huP[j], hvq = hvP[j];
+            if constexpr (MODE == MODE_RHS) { // (the RHS-only instance keeps the tests: with the selects it spilled 126-134 registers, 42 so)
+                if ((tags >> j) & 1) {
+                    huq = hu[m];
+                    hvq = hv[m];
+                    hq = HM[j] + vp.tide;
+                } else if (idx[j] < 0) {
+                    const double un = hu[m] * nxf + hv[m] * nyf;
+                    hq = h[m];
+                    huq = hu[m] - 2 * nxf * un;
+                    hvq = hv[m] - 2 * nyf * un;
+                }
+            } else {
+                const bool open = ((tags >> j) & 1) != 0, wall = (idx[j] < 0) & !open;
+                const double un2 = (open ? 0.0 : 2.0) * (hu[m] * nxf + hv[m] * nyf);   // open: the own momentum, wall: its mirror image
+                const bool own = open | wall;
+                hq = open ? HM[j] + vp.tide : (wall ? h[m] : hP[j]);
+                huq = own ? hu[m] - nxf * un2 : huP[j];
+                hvq = own ? hv[m] - nyf * un2 : hvP[j];
+            }
             const double bM = -HM[j], bP = -HP[j], mx = fmax(bP, bM);
             const double hMs = fmax(0.0, h[m] + bM - mx), hPs = fmax(0.0, hq + bP - mx);
             const double rM = fast_rcp(hMs), rP = fast_rcp(hPs);

@@ -11,6 +11,9 @@ mkdir -p "$OUT"
 rm -rf "$OUT"/prof_${TAG}_*
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/profiles/time_curved.py $ORDER $NX $NY"
+# BDG_COLLECT_CMD: another timing command with the same contract (last argument = number of evaluations / stages, one JSON line
+# with order and elements), e.g. "python3 profiles/time_stage_variant.py B 4 1000x500" with the kernel substring as fifth argument
+if [ -n "${BDG_COLLECT_CMD:-}" ]; then CMD="$BDG_COLLECT_CMD"; fi
 $CMD 40 > "$OUT/prof_${TAG}_warm.log" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_${TAG}_trace" -- $CMD 40 > "$OUT/prof_${TAG}_trace.log" 2>&1
 for group in "fetch:FETCH_SIZE" "write:WRITE_SIZE" "tcc:TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \

@@ -18,7 +18,8 @@ def jsonl(path):
 rows = jsonl(os.path.join(O, "curved_timings.jsonl"))
 old = os.path.join(P, f"{TAG}_curved_timings.json")
 keep = json.load(open(old)).get("round2_kernels_on_reference_rules", []) if os.path.exists(old) else []
-json.dump({"note": "ms per RHS evaluation of the curved / over-integrated solver (profiles/time_curved.py: deformed box, 5 % of the elements in curvedEls, "
+if rows:     # (a round that did not touch the curved kernels collects nothing for them)
+  json.dump({"note": "ms per RHS evaluation of the curved / over-integrated solver (profiles/time_curved.py: deformed box, 5 % of the elements in curvedEls, "
                    "midpoint RK2 + filter, tracer, drag array, bed slope), one box, final sources of the round. form = nodal-trace (default, "
                    "sw2d_curved_nt_kernel.hpp) or general (BDG_SW2D_CURVED_GENERAL=1: the round-2 stage kernels with this round's fix-up kernel). "
                    "round2_kernels_on_reference_rules: the round-2 code on the reference's cubature rules, measured at the start of round 3.",
@@ -54,6 +55,12 @@ while i < len(reh):
     else:
         i += 1
 lines.append("")
+ev = jsonl(os.path.join(O, "rehearsal_events.jsonl"))
+if ev:
+    lines.append("the same with the round-3 form of the dependencies (events on the queues, BDG_SW2D_EVENT_SYNC=1), same box, same call:")
+    for d in ev:
+        lines.append(f"N={d['order']} cells={d['cells']}: (rank, ms per stage) {[(r['rank'], round(r['ms_per_stage'], 4)) for r in d['ranks']]}")
+    lines.append("")
 for d in jsonl(os.path.join(O, "rehearsal_n4_w42.jsonl")):
     lines.append(f"N=4 world={d['world']}: {[(r['rank'], round(r['ms_per_stage'], 4)) for r in d['ranks']]}")
 lines += ["", "== kernel timeline of the 8-way rehearsal, rank 4 (rocprofv3 --kernel-trace): start us, duration us, end us", "-- N=4"]

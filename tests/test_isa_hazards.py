@@ -75,8 +75,13 @@ def test_no_matrix_instruction_overwrites_an_operand_it_is_still_reading(assembl
         # benchmark and every affine mesh run) must not spill at the highest order.
         spills = dict(re.findall(r"\.name:\s+(_ZN7bdg_dev23sw2d_stage_mfma3_kernel\w+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)",
                                  text))
-        plain = {k: int(v) for k, v in spills.items() if "ELb0ELb0ELb0E" in k}
-        assert len(plain) == 3 and not any(plain.values()), plain
+        # <N, MODE, HALO = false, NODAL = false, NFILT = false, SYNC>: the three modes, and the LSERK instance with in-kernel stage
+        # dependencies that the interior launches of a partitioned run take (round 4)
+        plain = {k: int(v) for k, v in spills.items() if re.search(r"ILi8ELi\dELb0ELb0ELb0ELb[01]EE", k)}
+        assert len(plain) == 4 and not any(plain.values()), plain
+        # the tracer as a second phase of every tile (round 4) prefetches during that phase: no spill there either
+        phase = dict(re.findall(r"\.name:\s+(_ZN7bdg_dev26sw2d_stage_mfma3src_kernelILi8ELi\dELb0ELi1ELb1E\w+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text))
+        assert len(phase) == 3 and not any(int(v) for v in phase.values()), phase
         # the per-node-geometry and halo forms give up the next-tile prefetch at this order for the same reason
         assert len(spills) >= 9 and max(int(v) for v in spills.values()) <= 16, spills
 

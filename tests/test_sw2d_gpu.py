@@ -678,11 +678,11 @@ def test_cpp_driver_sw2d_tidal_matches_oracle_replay(mode, coarse_mesh):
 
 @pytest.mark.parametrize("variant", [8, 9])
 @pytest.mark.parametrize("order,nx,ny,seed", [(2, 37, 23, 0), (4, 41, 29, 0), (4, 41, 29, 9), (5, 19, 13, 0)])
-def test_round4_ab_variants_equal_the_unrolled_kernel_bit_for_bit(variant, order, nx, ny, seed, monkeypatch):
-    """BDG_SW2D_AFFINE_VARIANT=8 (state-resident kernel at two waves per SIMD, sw2d_affine_lean_kernel.hpp) and =9 (neighbour traces
-    of in-wave faces exchanged through LDS, sw2d_affine_xchg_kernel.hpp): the same node-by-node arithmetic as the unrolled kernel
-    (variant 0) -- 11 LSERK4 stages on a mesh of several dozen waves with a ragged last one, natural order (most neighbours inside
-    the wave) and shuffled (hardly any), must leave identical bits."""
+def test_round4_ab_variants_equal_the_unrolled_kernel(variant, order, nx, ny, seed, monkeypatch):
+    """BDG_SW2D_AFFINE_VARIANT=9 (neighbour traces of in-wave faces exchanged through LDS, sw2d_affine_xchg_kernel.hpp): the unrolled
+    kernel's arithmetic in the unrolled kernel's order -- 11 LSERK4 stages on a mesh of several dozen waves with a ragged last one,
+    natural order (most neighbours inside the wave) and shuffled (hardly any), must leave identical bits. =8 (state-resident kernel
+    at two waves per SIMD, sw2d_affine_lean_kernel.hpp) adds the volume term before the surface term: equal to round-off."""
     m = dg.MeshManager()
     m.buildBoxMesh(nx, ny, shuffleSeed=seed)
     nodes = dg.TriangleNodesProvisioner(order, m)
@@ -700,7 +700,10 @@ def test_round4_ab_variants_equal_the_unrolled_kernel_bit_for_bit(variant, order
         s.close()
     assert np.abs(out[0][1] - q0[1]).max() > 1e-6
     for a, b in zip(out[variant], out[0]):
-        assert np.array_equal(a, b)
+        if variant == 9:
+            assert np.array_equal(a, b)
+        else:
+            assert np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
 
 
 @pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
