@@ -148,6 +148,9 @@ _SIGNATURES = {
     "bdg_lserk4_a": (POINTER(c_double), []),
     "bdg_lserk4_b": (POINTER(c_double), []),
     "bdg_nodes1d_advec_rhs": (c_int, [_P, _P, c_double, _P]),
+    "bdg_nodes1d_burgers_rhs": (c_int, [_P, _P, c_double, c_double, c_double, c_double, _P]),
+    "bdg_burgers1d_run": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double, c_double, c_double,
+                                  POINTER(c_double), POINTER(c_int)]),
     "bdg_advec1d_run": (c_int, [c_int, c_int, c_double, c_double, c_double, c_double, c_double,
                                 POINTER(c_double), POINTER(c_int)]),
     "bdg_device_count": (c_int, []),

@@ -5,6 +5,7 @@
 #include "capi_internal.hpp"
 #include "parallel_for.hpp"
 #include "blitzdg/Advec1d.hpp"
+#include "blitzdg/Burgers1d.hpp"
 #include "blitzdg/LSERK4.hpp"
 #include "blitzdg/TriangleCubatureRules.hpp"
 #include "blitzdg/VtkOutputter.hpp"
@@ -574,6 +575,30 @@ int bdg_advec1d_run(int order, int K, double xmin, double xmax, double c, double
         if (!max_error || order < 1 || K < 1 || c == 0.0) throw bdg_detail::arg_error("bdg_advec1d_run: bad argument");
         index_type steps = 0;
         *max_error = advec1d::run(order, K, xmin, xmax, c, cfl, final_time, &steps);
+        if (num_steps) *num_steps = steps;
+    });
+}
+
+int bdg_nodes1d_burgers_rhs(bdg_nodes1d* nodes, const double* u, double t, double c, double alpha, double nu, double* rhs) {
+    return guard([&] {
+        if (!nodes || !u || !rhs) throw bdg_detail::arg_error("bdg_nodes1d_burgers_rhs: NULL argument");
+        if (alpha == 0.0 || nu <= 0.0) throw bdg_detail::arg_error("bdg_nodes1d_burgers_rhs: need alpha != 0 and nu > 0");
+        auto& p = nodes->prov;
+        const int Np = p.get_NumLocalPoints(), K = p.get_NumElements();
+        real_matrix_type um(Np, K), out(Np, K);
+        std::copy(u, u + static_cast<size_t>(Np) * K, um.data());
+        blitzdg::burgers1d::computeRHS(um, p.get_xGrid(), t, c, alpha, nu, p, out);
+        std::copy(out.data(), out.data() + static_cast<size_t>(Np) * K, rhs);
+    });
+}
+
+int bdg_burgers1d_run(int order, int K, double xmin, double xmax, double alpha, double nu, double c, double cfl, double final_time,
+                      double* max_error, int* num_steps) {
+    return guard([&] {
+        if (!max_error || order < 1 || K < 1 || c == 0.0 || alpha == 0.0 || nu <= 0.0)
+            throw bdg_detail::arg_error("bdg_burgers1d_run: bad argument");
+        index_type steps = 0;
+        *max_error = burgers1d::run(order, K, xmin, xmax, alpha, nu, c, cfl, final_time, &steps);
         if (num_steps) *num_steps = steps;
     });
 }

@@ -445,6 +445,24 @@ def advec1dRun(N=4, K=30, xmin=-1.0, xmax=4.0, c=0.1, CFL=0.8, finalTime=20.0):
     return err.value, steps.value
 
 
+def burgers1dComputeRHS(u, t, c, alpha, nu, nodes1d):
+    """blitzdg::burgers1d::computeRHS (src/burgers1d/main.cpp:129-226) on the provisioner's own grid: viscous Burgers as a first-order
+    system, local Lax-Friedrichs flux, the travelling wave as boundary data. Host code (CPU plumbing beside advec1d)."""
+    Np, K = nodes1d.numLocalPoints, nodes1d.numElements
+    ua = C.as_f64(u, (Np, K), "u")
+    out = np.empty((Np, K))
+    check(lib.bdg_nodes1d_burgers_rhs(nodes1d._h, C.ptr(ua), float(t), float(c), float(alpha), float(nu), C.ptr(out)))
+    return out
+
+
+def burgers1dRun(N=6, K=40, xmin=-5.0, xmax=5.0, alpha=1.0, nu=0.1, c=0.5, CFL=0.75, finalTime=0.1):
+    """The reference's bin/burgers1d (src/burgers1d/main.cpp:28-115, its constants as defaults); host-only LSERK4 loop.
+    Returns (max-norm error vs the travelling wave, number of steps)."""
+    err, steps = c_double(), c_int()
+    check(lib.bdg_burgers1d_run(N, K, xmin, xmax, alpha, nu, c, CFL, finalTime, byref(err), byref(steps)))
+    return err.value, steps.value
+
+
 class VtkOutputter:
     """Writes nodal fields as *.vtu files for Paraview; names of the reference's binding
     (src/pyblitzdg/pyblitzdg.cpp:189-192). No VTK library involved."""

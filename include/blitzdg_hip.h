@@ -198,6 +198,13 @@ int bdg_nodes1d_advec_rhs(bdg_nodes1d* nodes, const double* u, double c, double*
 int bdg_advec1d_run(int order, int num_elements, double xmin, double xmax, double c, double cfl,
                     double final_time, double* max_error, int* num_steps);
 
+/* burgers1d: the second 1-D solver on Nodes1DProvisioner + LSERK4 (reference src/burgers1d/main.cpp:28-115 driver, :129-226
+ * RHS). Host only. rhs: burgers1d::computeRHS(u, x, t, c, alpha, nu, nodes1D, RHS) with x the provisioner's own grid;
+ * run: the driver loop to t >= final_time, max-norm error against the travelling wave Burgers2. */
+int bdg_nodes1d_burgers_rhs(bdg_nodes1d* nodes, const double* u, double t, double c, double alpha, double nu, double* rhs);
+int bdg_burgers1d_run(int order, int num_elements, double xmin, double xmax, double alpha, double nu, double c, double cfl,
+                      double final_time, double* max_error, int* num_steps);
+
 /* ---------------------------------------------------------------- sw2d device solver */
 
 /* Host tables a solver is created from (all borrowed for the duration of the call). */

@@ -290,3 +290,36 @@ def sw2d_rhs_curved(h, hu, hv, hN, zx, zy, g, f, CD, t):
     out[1] -= g * h * zx
     out[2] -= g * h * zy
     return tuple(out)
+
+
+# ---- burgers1d (reference src/burgers1d/main.cpp:119-226): the RHS in NumPy, operation for operation. Test infrastructure only.
+# parity unpinned: the reference holds no vector for this solver and its C++ cannot be built here (blitz++, boost absent); the
+# restatement and the host code are two independent readings of the same file, checked against each other and against the
+# travelling-wave solution the driver itself prints its error against.
+
+def burgers2(x, t, alpha, nu, c):
+    """main.cpp:119-126."""
+    return (c / alpha) - (c / alpha) * np.tanh(0.5 * (c / nu) * (x - c * t))
+
+
+def burgers1d_rhs(u, x, t, c, alpha, nu, Dr, rx, Lift, Fscale, nx, vmapM, vmapP, mapI, mapO, vmapI, vmapO):
+    """main.cpp:129-226; every (rows, K) table C-ordered, index maps on the column-wise flattening (byRows = false)."""
+    F = lambda a: np.asarray(a).flatten("F")                      # noqa: E731  fullToVector(.., false)
+    shape = np.asarray(nx).shape
+    M = lambda v: np.reshape(v, shape, order="F")                 # noqa: E731  vectorToFull(.., false)
+    uVec, xVec, nxVec = F(u), F(x), F(nx)
+    uM, uP = uVec[vmapM], uVec[vmapP]
+    maxvel = np.max(np.abs(u))
+    uL, uR = burgers2(xVec[vmapI], t, alpha, nu, c), burgers2(xVec[vmapO], t, alpha, nu, c)
+    du = uM - uP
+    du[mapI] = 2 * (uVec[vmapI] - uL)
+    du[mapO] = 2 * (uVec[vmapO] - uR)
+    q = np.sqrt(nu) * (rx * np.dot(Dr, u) - np.dot(Lift, 0.5 * Fscale * nx * M(du)))
+    qVec = F(q)
+    dq = 0.5 * (qVec[vmapM] - qVec[vmapP])
+    dq[mapI] = dq[mapO] = 0.0
+    du2 = 0.5 * (uM * uM - uP * uP)
+    du2[mapI] = uVec[vmapI] * uVec[vmapI] - uL * uL
+    du2[mapO] = uVec[vmapO] * uVec[vmapO] - uR * uR
+    flux = nxVec * (0.5 * du2 - np.sqrt(nu) * dq) - (0.5 * maxvel) * du
+    return -rx * np.dot(Dr, 0.5 * u * u - np.sqrt(nu) * q) + np.dot(Lift, Fscale * M(flux))
