@@ -91,6 +91,10 @@ def committed_traffic(order, elements):
             d = json.load(open(f))
             if d.get("kernel_source_sha") != sha or d.get("order") != order or d.get("elements") != elements:
                 continue
+            # only the default three-field stage kernels (profiles/ also holds collections of variant B, the tracer phase, A/B variants)
+            kern = d.get("kernel") or ""
+            if not ("sw2d_stage_affine_kernel<" in kern or "sw2d_stage_mfma3_kernel<" in kern or "sw2d_stage_mfma_kernel<" in kern):
+                continue
             return d["hbm_traffic_per_launch"]["total_bytes"], os.path.basename(f)
         except (KeyError, ValueError, OSError):
             continue
