@@ -154,7 +154,7 @@ def stage_kernel_name(order, elements, affine):
     forced = os.environ.get("BDG_SW2D_AFFINE_VARIANT")
     if forced is not None:
         return f"BDG_SW2D_AFFINE_VARIANT={forced} <{order}, MODE_LSERK>"
-    small = {1: 4000, 2: 10000, 3: 100000, 4: 160000}
+    small = {1: 4000, 2: 10000, 3: 160000, 4: 160000}
     if order >= 5:
         return f"sw2d_stage_mfma3_kernel<{order}, MODE_LSERK>"
     if elements < small[order]:

@@ -497,7 +497,10 @@ struct bdg_sw2d {
     // elements below which the matrix-core kernel is the faster one, per order (measured crossovers:
     // N=2 near 10 k, N=3 near 125 k, N=4 between 125 k and 250 k; N=1 never ahead; N=5 runs on
     // the matrix cores at every size)
-    static constexpr int kSmallLaunch[6] = {0, 4000, 10000, 100000, 160000, 0};
+    // (round 4, after the matrix-core kernel of N <= 4 got all its requests ahead of its first product -- kernel ms, unrolled / matrix cores,
+    // profiles/r04_rehearsal_experiments.txt: N=4 125 k elements 0.0543 / 0.0452, 250 k 0.1009 / 0.1142; N=3 125 k 0.0365 / 0.0313, 250 k 0.0612 /
+    // 0.0704; N=2 125 k 0.0189 / 0.0283: N=3's crossover moves up to where N=4's is)
+    static constexpr int kSmallLaunch[6] = {0, 4000, 10000, 160000, 160000, 0};
     bool variantForced = false;                 // BDG_SW2D_AFFINE_VARIANT given
     // resident-workgroup kernels, interior launch of a partitioned run: CUs left to the boundary kernel (a strip of a few
     // hundred elements = 4..8 four-wave workgroups); N=8, 8-way rehearsal: 0.087 -> see profiles/r02_rehearsal.txt

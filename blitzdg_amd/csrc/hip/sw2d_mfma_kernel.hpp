@@ -69,8 +69,10 @@ struct MfmaOps {
 // elements next to the partition boundary -- wait for the previous stage's boundary launch before they read or write anything
 // and signal when their stores are visible; a boundary launch (HALO) waits for the previous interior launch's ring tiles at
 // its top and signals once per workgroup at its end.
+// (N <= 4: the register budget of two waves per SIMD -- with every request ahead of the first product the kernel sits at 232-241
+// vector registers beside its 24 accumulation registers, a few above the 256 that two waves may hold together)
 template <int N, int MODE, bool HALO = false, bool SYNC = false>
-__global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(const StageParams p) {
+__global__ __launch_bounds__(256, (N <= 4 ? 2 : BDG_MFMA_WAVES)) void sw2d_stage_mfma_kernel(const StageParams p) {
     using E = Elem<N>;
     using O = MfmaOps<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN, MT = O::MT, KV = O::KV, KS = O::KS;
@@ -107,6 +109,74 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
         const unsigned k = live ? kTrue : kLast; // padding lanes recompute the last element, store nothing
         const unsigned k8 = k * 8u, k4 = k * 4u;
 
+        // Round 4: everything the tile reads is REQUESTED in dependency order before the first product -- indices, geometry, own
+        // rows of the volume steps and of the face nodes; then the neighbour traces (they need the indices) while the volume
+        // operands are formed; the update's rows (state again, residual) behind the volume products -- instead of where each value
+        // is first used. A wave of this kernel runs ONE tile of a small launch (a rank's share of a many-way split, its boundary
+        // strip): its time is the chain of dependent round trips, which this order cuts from four or five to two. No request sits
+        // inside a lane-dependent branch (padding rows / face nodes beyond the element read a valid address and are ignored).
+        // Same arithmetic in the same order as before: results are bit-identical.
+        int id[KS];
+        unsigned mface[KS];
+        int fidx[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const int jf = 4 * t + static_cast<int>(q), jc = jf < NFN ? jf : 0;
+            fidx[t] = jc / Nfp;
+            mface[t] = static_cast<unsigned>(fmask_rt<N>(fidx[t], jc - fidx[t] * Nfp));
+            id[t] = ld_row(p.vmapP + jc * ld, k4);
+        }
+        const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8), sy = ld_row(ag + 3 * ld, k8);
+        const double hf0 = 0.5 * ld_row(ag + 10 * ld, k8), hf1 = 0.5 * ld_row(ag + 11 * ld, k8), hf2 = 0.5 * ld_row(ag + 12 * ld, k8);
+        double vh[KV], vhu[KV], vhv[KV];
+#pragma unroll
+        for (int t = 0; t < KV; ++t) {
+            const int m = 4 * t + static_cast<int>(q), mc = m < Np ? m : 0;
+            vh[t] = ld_row(qin + mc * ld, k8);
+            vhu[t] = ld_row(qin + plane + mc * ld, k8);
+            vhv[t] = ld_row(qin + 2 * plane + mc * ld, k8);
+        }
+        double nxv[KS], nyv[KS], hMv[KS], huMv[KS], hvMv[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            nxv[t] = ld_row(ag + (4 + fidx[t]) * ld, k8);
+            nyv[t] = ld_row(ag + (7 + fidx[t]) * ld, k8);
+            hMv[t] = ld_row(qin + static_cast<long long>(mface[t]) * ld, k8);
+            huMv[t] = ld_row(qin + plane + static_cast<long long>(mface[t]) * ld, k8);
+            hvMv[t] = ld_row(qin + 2 * plane + static_cast<long long>(mface[t]) * ld, k8);
+        }
+        int sendRec[3] = {-1, -1, -1};
+        if constexpr (HALO) {
+            const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
+            sendRec[0] = p.haloSendOf[b3];
+            sendRec[1] = p.haloSendOf[b3 + 1];
+            sendRec[2] = p.haloSendOf[b3 + 2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- neighbour ('+') traces: from the state planes, or (HALO) from the received record of a ghost element
+        double hqv[KS], huqv[KS], hvqv[KS];
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            const unsigned idp = static_cast<unsigned>(id[t] < 0 ? -(id[t] + 1) : id[t]);
+            const double* b0 = qin;
+            const double* b1 = qin + plane;
+            const double* b2 = qin + 2 * plane;
+            unsigned o8 = idp * 8u;
+            if constexpr (HALO) {
+                const unsigned row = idp / static_cast<unsigned>(ld), slot = idp - row * static_cast<unsigned>(ld);
+                const bool ghost = slot >= static_cast<unsigned>(p.haloOwned);
+                const unsigned rec8 = ((slot - static_cast<unsigned>(p.haloOwned)) * static_cast<unsigned>(p.haloRows) + row) * 8u;
+                b0 = ghost ? p.haloRecv : b0;            // the neighbour's record as it arrived: [field][node]
+                b1 = ghost ? p.haloRecv + Np : b1;
+                b2 = ghost ? p.haloRecv + 2 * Np : b2;
+                o8 = ghost ? rec8 : o8;
+            }
+            hqv[t] = ld_row(b0, o8);
+            huqv[t] = ld_row(b1, o8);
+            hvqv[t] = ld_row(b2, o8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
         mfma_acc_t acc[3][MT];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
@@ -114,37 +184,55 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
             for (int r = 0; r < MT; ++r) acc[c][r] = mfma_acc_t{0.0, 0.0, 0.0, 0.0};
 
         // ---- volume term: k-steps of 4 input nodes, this lane supplies node m = 4t + q
-        {
-            const double rx = ld_row(ag, k8), sx = ld_row(ag + ld, k8), ry = ld_row(ag + 2 * ld, k8),
-                         sy = ld_row(ag + 3 * ld, k8);
 #pragma unroll
-            for (int t = 0; t < KV; ++t) {
-                const int m = 4 * t + static_cast<int>(q);
-                double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
-                if (m < Np) {
-                    const double h = ld_row(qin + m * ld, k8), hu = ld_row(qin + plane + m * ld, k8),
-                                 hv = ld_row(qin + 2 * plane + m * ld, k8);
-                    const double r = fast_rcp(h);
-                    const double u = hu * r, v = hv * r;
-                    const double pr = halfg * h * h;
-                    const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
-                    a1 = -(rx * hu + ry * hv); b1 = -(sx * hu + sy * hv);
-                    a2 = -(rx * F2 + ry * G2); b2 = -(sx * F2 + sy * G2);
-                    a3 = -(rx * G2 + ry * G3); b3 = -(sx * G2 + sy * G3);
-                }
+        for (int t = 0; t < KV; ++t) {
+            const int m = 4 * t + static_cast<int>(q);
+            double a1 = 0, b1 = 0, a2 = 0, b2 = 0, a3 = 0, b3 = 0;
+            {
+                const bool pad = m >= Np;
+                const double h = pad ? 1.0 : vh[t], hu = vhu[t], hv = vhv[t];
+                const double r = fast_rcp(h);
+                const double u = hu * r, v = hv * r;
+                const double pr = halfg * h * h;
+                const double F2 = hu * u + pr, G2 = hu * v, G3 = hv * v + pr;
+                const double a1n = -(rx * hu + ry * hv), b1n = -(sx * hu + sy * hv);
+                const double a2n = -(rx * F2 + ry * G2), b2n = -(sx * F2 + sy * G2);
+                const double a3n = -(rx * G2 + ry * G3), b3n = -(sx * G2 + sy * G3);
+                a1 = pad ? 0.0 : a1n; b1 = pad ? 0.0 : b1n;
+                a2 = pad ? 0.0 : a2n; b2 = pad ? 0.0 : b2n;
+                a3 = pad ? 0.0 : a3n; b3 = pad ? 0.0 : b3n;
+            }
 #pragma unroll
-                for (int r = 0; r < MT; ++r) {
-                    const double Adr = sOps[O::OFF_DR + (r * KV + t) * 64 + lane];
-                    const double Ads = sOps[O::OFF_DS + (r * KV + t) * 64 + lane];
-                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a1, acc[0][r], 0, 0, 0);
-                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a2, acc[1][r], 0, 0, 0);
-                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a3, acc[2][r], 0, 0, 0);
-                    acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b1, acc[0][r], 0, 0, 0);
-                    acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b2, acc[1][r], 0, 0, 0);
-                    acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b3, acc[2][r], 0, 0, 0);
-                }
+            for (int r = 0; r < MT; ++r) {
+                const double Adr = sOps[O::OFF_DR + (r * KV + t) * 64 + lane];
+                const double Ads = sOps[O::OFF_DS + (r * KV + t) * 64 + lane];
+                acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a1, acc[0][r], 0, 0, 0);
+                acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a2, acc[1][r], 0, 0, 0);
+                acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, a3, acc[2][r], 0, 0, 0);
+                acc[0][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b1, acc[0][r], 0, 0, 0);
+                acc[1][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b2, acc[1][r], 0, 0, 0);
+                acc[2][r] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, b3, acc[2][r], 0, 0, 0);
             }
         }
+
+        // ---- the update's inputs: requested now, land during the surface term. The element's own state at this lane's OUTPUT nodes
+        //      i = 16 r + q + 4 reg is what the volume steps already hold -- node m = 4 t + q with t = 4 r + reg -- so it is not read again.
+        double oldv[3][MT][4];
+        if constexpr (MODE != MODE_RHS) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const long long fo = static_cast<long long>(c) * plane;
+                const double* __restrict__ base2 = ((MODE == MODE_LSERK) ? p.res : p.qbase) + fo;
+#pragma unroll
+                for (int r = 0; r < MT; ++r)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int i = 16 * r + static_cast<int>(q) + 4 * reg, ic = i < Np ? i : 0;
+                        oldv[c][r][reg] = ld_row(base2 + ic * ld, k8);
+                    }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 
         // ---- surface term: k-steps of 4 face nodes, this lane supplies face node jf = 4t + q
         {
@@ -156,30 +244,12 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
                 e1[t] = e2[t] = e3[t] = d1[t] = d2[t] = d3[t] = 0.0;
                 spd[t] = 0.0;
                 if (jf < NFN) {
-                    const int f = jf / Nfp, n = jf - f * Nfp, m = fmask_rt<N>(f, n);
-                    const double nxf = ld_row(ag + (4 + f) * ld, k8), nyf = ld_row(ag + (7 + f) * ld, k8);
-                    const int id = ld_row(p.vmapP + jf * ld, k4);
-                    const double hM = ld_row(qin + m * ld, k8), huM = ld_row(qin + plane + m * ld, k8),
-                                 hvM = ld_row(qin + 2 * plane + m * ld, k8);
-                    const unsigned idp = static_cast<unsigned>(id < 0 ? -(id + 1) : id), o8 = idp * 8u;
-                    double hq, huq, hvq;
-                    bool ghost = false;
-                    unsigned rec8 = 0;
-                    if constexpr (HALO) {
-                        const unsigned row = idp / static_cast<unsigned>(ld), slot = idp - row * static_cast<unsigned>(ld);
-                        ghost = slot >= static_cast<unsigned>(p.haloOwned);
-                        rec8 = ((slot - static_cast<unsigned>(p.haloOwned)) * static_cast<unsigned>(p.haloRows) + row) * 8u;
-                    }
-                    if (ghost) { // the neighbour's record as it arrived: [field][node]
-                        hq = ld_row(p.haloRecv, rec8);
-                        huq = ld_row(p.haloRecv + Np, rec8);
-                        hvq = ld_row(p.haloRecv + 2 * Np, rec8);
-                    } else {
-                        hq = ld_row(qin, o8);
-                        huq = ld_row(qin + plane, o8);
-                        hvq = ld_row(qin + 2 * plane, o8);
-                    }
-                    if (id < 0) { // reflective wall: no normal flow
+                    const int f = fidx[t];
+                    const double nxf = nxv[t], nyf = nyv[t];
+                    const double hM = hMv[t], huM = huMv[t], hvM = hvMv[t];
+                    const double hq = hqv[t];
+                    double huq = huqv[t], hvq = hvqv[t];
+                    if (id[t] < 0) { // reflective wall: no normal flow
                         const double un = huM * nxf + hvM * nyf;
                         huq = huM - 2 * nxf * un;
                         hvq = hvM - 2 * nyf * un;
@@ -207,8 +277,6 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
                 lamF[f] = fmax(lamF[f], __shfl_xor(lamF[f], 16));
                 lamF[f] = fmax(lamF[f], __shfl_xor(lamF[f], 32));
             }
-            const double hf0 = 0.5 * ld_row(ag + 10 * ld, k8), hf1 = 0.5 * ld_row(ag + 11 * ld, k8),
-                         hf2 = 0.5 * ld_row(ag + 12 * ld, k8);
 #pragma unroll
             for (int t = 0; t < KS; ++t) {
                 const int jf = 4 * t + static_cast<int>(q);
@@ -230,40 +298,23 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
 
         // ---- stage update / output: this lane holds output nodes i = 16r + q + 4*reg of its element
         if (live) {
-            int sendRec[3] = {-1, -1, -1};
-            if constexpr (HALO) {
-                const unsigned b3 = (k - static_cast<unsigned>(p.kbegin)) * 3u;
-                sendRec[0] = p.haloSendOf[b3];
-                sendRec[1] = p.haloSendOf[b3 + 1];
-                sendRec[2] = p.haloSendOf[b3 + 2];
-            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const long long fo = static_cast<long long>(c) * plane;
 #pragma unroll
                 for (int r = 0; r < MT; ++r) {
-                    double oldv[4], qv[4];
-                    if constexpr (MODE != MODE_RHS) {
-                        const double* __restrict__ base2 = ((MODE == MODE_LSERK) ? p.res : p.qbase) + fo;
-#pragma unroll
-                        for (int reg = 0; reg < 4; ++reg) {
-                            const int i = 16 * r + static_cast<int>(q) + 4 * reg;
-                            if (i < Np) {
-                                qv[reg] = ld_row(qin + fo + i * ld, k8);
-                                oldv[reg] = ld_row(base2 + i * ld, k8);
-                            }
-                        }
-                    }
 #pragma unroll
                     for (int reg = 0; reg < 4; ++reg) {
                         const int i = 16 * r + static_cast<int>(q) + 4 * reg;
                         if (i < Np) {
                             const double R = acc[c][r][reg];
+                            const int ts = 4 * r + reg;                                    // (i < Np implies ts < KV)
+                            const double own = c == 0 ? vh[ts < KV ? ts : 0] : (c == 1 ? vhu[ts < KV ? ts : 0] : vhv[ts < KV ? ts : 0]);
                             if constexpr (MODE == MODE_RHS) {
                                 st_row(p.rhs + fo + i * ld, k8, R);
                             } else if constexpr (MODE == MODE_LSERK) {
-                                const double n1 = p.ca * oldv[reg] + p.cc * R;
-                                const double qn = qv[reg] + p.cb * n1;
+                                const double n1 = p.ca * oldv[c][r][reg] + p.cc * R;
+                                const double qn = own + p.cb * n1;
                                 st_row(p.res + fo + i * ld, k8, n1);
                                 if constexpr (SYNC) { // a tile that signals hands its new state to the other chain: write-through
                                     if (HALO || tile >= static_cast<unsigned>(p.syncFirstTile)) st_row_wt(p.qout + fo + i * ld, k8, qn);
@@ -278,7 +329,7 @@ __global__ __launch_bounds__(256, BDG_MFMA_WAVES) void sw2d_stage_mfma_kernel(co
                                             p.haloSend[static_cast<size_t>(sendRec[sr]) * p.haloRows + c * Np + i] = qn;
                                 }
                             } else {
-                                const double val = p.ca * oldv[reg] + p.cb * qv[reg] + p.cc * R;
+                                const double val = p.ca * oldv[c][r][reg] + p.cb * own + p.cc * R;
                                 st_row(p.qout + fo + i * ld, k8, c == 0 ? val : sponge_relax(val, p.sponge));
                             }
                         }

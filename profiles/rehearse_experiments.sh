@@ -10,6 +10,6 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 for spec in "$@"; do
   set -- $spec
   n=$1; cells=$2; shift 2
-  line=$(env "$@" BDG_REHEARSE_RANKS=${RANKS:-4} timeout -k 10 240 python3 bench.py --rehearse-world 8 --steps 40 --warmup 10 --order $n --cells $cells 2>/dev/null | grep '^{' | python3 -c 'import sys, json; d = json.loads(sys.stdin.read()); print(" ".join("%.4f" % r["ms_per_stage"] for r in d["ranks"]))')
+  line=$(env "$@" BDG_REHEARSE_RANKS=${RANKS:-4} timeout -k 10 240 python3 bench.py --rehearse-world 8 --steps ${STEPS:-40} --warmup 10 --order $n --cells $cells 2>/dev/null | grep '^{' | python3 -c 'import sys, json; d = json.loads(sys.stdin.read()); print(" ".join("%.4f" % r["ms_per_stage"] for r in d["ranks"]))')
   echo "N=$n $cells [$*] ms per stage: $line" | tee -a "$OUT"
 done
