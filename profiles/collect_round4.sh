@@ -13,17 +13,17 @@ export HSA_ENABLE_IPC_MODE_LEGACY=0
 cd "$R"
 for n in 4 5 6 7 8; do
   cells=$([ $n = 4 ] && echo 1000x500 || ([ $n = 5 ] && echo 800x400 || ([ $n = 6 ] && echo 1000x250 || echo 500x250)))
-  BDG_REHEARSE_RANKS=0,1,4 python3 bench.py --rehearse-world 8 --steps 40 --warmup 10 --order $n --cells $cells 2>/dev/null | grep '^{'
+  BDG_REHEARSE_RANKS=0,1,4 python3 bench.py --rehearse-world 8 --steps 200 --warmup 20 --order $n --cells $cells 2>/dev/null | grep '^{'
   python3 bench.py --order $n --cells $cells --steps 100 --warmup 20 --no-cpu-baseline --no-also 2>/dev/null | grep '^{'
 done > "$OUT/rehearsal.jsonl"
 for n in 4 8; do
   cells=$([ $n = 4 ] && echo 1000x500 || echo 500x250)
-  BDG_SW2D_EVENT_SYNC=1 BDG_REHEARSE_RANKS=0,1,4 python3 bench.py --rehearse-world 8 --steps 40 --warmup 10 --order $n --cells $cells 2>/dev/null | grep '^{'
+  BDG_SW2D_EVENT_SYNC=1 BDG_REHEARSE_RANKS=0,1,4 python3 bench.py --rehearse-world 8 --steps 200 --warmup 20 --order $n --cells $cells 2>/dev/null | grep '^{'
 done > "$OUT/rehearsal_events.jsonl"
-for w in 4 2; do BDG_REHEARSE_RANKS=0,1 python3 bench.py --rehearse-world $w --steps 40 --warmup 10 2>/dev/null | grep '^{'; done > "$OUT/rehearsal_n4_w42.jsonl"
+for w in 4 2; do BDG_REHEARSE_RANKS=0,1 python3 bench.py --rehearse-world $w --steps 200 --warmup 20 2>/dev/null | grep '^{'; done > "$OUT/rehearsal_n4_w42.jsonl"
 ( cd /tmp && export TMPDIR=/tmp && for n in 4 8; do
     cells=$([ $n = 4 ] && echo 1000x500 || echo 500x250)
-    BDG_REHEARSE_RANKS=4 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/reh_trace_n$n" -- python3 "$R/bench.py" --rehearse-world 8 --steps 40 --warmup 10 --order $n --cells $cells > /dev/null 2>&1
+    BDG_REHEARSE_RANKS=4 timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d "$OUT/reh_trace_n$n" -- python3 "$R/bench.py" --rehearse-world 8 --steps 200 --warmup 20 --order $n --cells $cells > /dev/null 2>&1
     python3 "$R/profiles/timeline.py" "$OUT/reh_trace_n$n" > "$OUT/timeline_n$n.txt" 2>&1
     rm -rf "$OUT/reh_trace_n$n"
   done )

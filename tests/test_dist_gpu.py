@@ -303,6 +303,40 @@ def test_loopback_rccl_in_kernel_dependencies_equal_the_event_form(order, shape,
             assert np.array_equal(a, b), (order, attempt)
 
 
+_BOUNDED_WAIT_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np
+from blitzdg_amd._capi import BdgError
+from test_dist_gpu import _loopback_run
+try:
+    got = _loopback_run(8, (120, 80), chunks=(2,))
+    np.savez(sys.argv[2], *got)
+    print("finished")
+except BdgError as e:
+    print("reported:", e)
+"""
+
+
+def test_in_kernel_wait_is_bounded_and_reported(tmp_path):
+    """The safety net of the in-kernel dependencies: with the interior launch pinned to ALL 256 compute units at N = 8 (BDG_SW2D_INTERIOR_CAP=256;
+    its workgroups hold 120 KB of LDS each, so the boundary launch's workgroups fit nowhere) the ring tiles can wait for a boundary launch that
+    cannot start. The wait is bounded (sync_wait gives up after 2^21 polls, marks the run and goes on), so the device never hangs: either the
+    hardware found room anyway and the result equals the event form's, or the next synchronisation reports the time-out as an error.
+    (Child processes: the cap is read once per process.)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("BDG_SW2D_STRIP_THROUGHPUT", "BDG_SW2D_HALO_KERNELS", "BDG_SW2D_EVENT_SYNC")}
+    ref = launch([sys.executable, "-c", _BOUNDED_WAIT_SCRIPT, ROOT, str(tmp_path / "ref.npz")], env=dict(env, BDG_SW2D_EVENT_SYNC="1"), timeout=300)
+    assert ref.returncode == 0 and "finished" in ref.stdout, ref.stdout + ref.stderr
+    out = launch([sys.executable, "-c", _BOUNDED_WAIT_SCRIPT, ROOT, str(tmp_path / "capped.npz")], env=dict(env, BDG_SW2D_INTERIOR_CAP="256"), timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if "reported:" in out.stdout:
+        assert "timed out" in out.stdout
+        return
+    a, b = np.load(tmp_path / "ref.npz"), np.load(tmp_path / "capped.npz")
+    for key in a.files:
+        assert np.array_equal(a[key], b[key])
+
+
 # ---- the real multi-process path (one process per rank, the library's own communicator and stage loop) with a
 # ---- file-based stand-in for librccl.so, so that the ranks can share the single GPU of a test box
 
