@@ -1936,6 +1936,8 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         s->commRank = rank;
         s->commWorld = world;
         s->peers = peers;
+        // (default priority: at the highest priority every stage of every order took about twice as long -- 8-way N=4 0.0958 against 0.0483 ms,
+        // N=8 0.113 against 0.052, 2-way 0.293 against 0.205: profiles/r04_rehearsal_experiments.txt, call 28)
         hipCheck(hipStreamCreateWithFlags(&s->commStream, hipStreamNonBlocking), "hipStreamCreate");
         // These four events only order kernels of the two streams of THIS device against each other (a kernel's own
         // end-of-kernel release is device-wide, and data from another GPU is made visible by the RCCL kernel that received

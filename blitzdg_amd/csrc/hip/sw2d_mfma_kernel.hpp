@@ -71,21 +71,26 @@ struct MfmaOps {
 // its top and signals once per workgroup at its end.
 // (N <= 4: the register budget of two waves per SIMD -- with every request ahead of the first product the kernel sits at 232-241
 // vector registers beside its 24 accumulation registers, a few above the 256 that two waves may hold together)
-template <int N, int MODE, bool HALO = false, bool SYNC = false>
-__global__ __launch_bounds__(256, (N <= 4 ? 2 : BDG_MFMA_WAVES)) void sw2d_stage_mfma_kernel(const StageParams p) {
+// THREADS = 64 (boundary launches of N <= 4): one-wave workgroups. A 256-thread workgroup needs register room on all four SIMDs of a CU at
+// the same moment; beside an interior launch on the unrolled kernel -- one-wave workgroups of 410 registers that the dispatcher replaces one by
+// one -- that moment never comes before the interior grid is exhausted, and the boundary chain of a 2- or 4-way stage ran BEHIND the interior
+// launch instead of beside it. A one-wave workgroup takes the first SIMD that falls free.
+template <int N, int MODE, bool HALO = false, bool SYNC = false, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, (N <= 4 ? 2 : BDG_MFMA_WAVES)) void sw2d_stage_mfma_kernel(const StageParams p) {
+    constexpr unsigned WAVES = THREADS / 64;
     using E = Elem<N>;
     using O = MfmaOps<N>;
     constexpr int Np = E::Np, Nfp = E::Nfp, NFN = E::NFN, MT = O::MT, KV = O::KV, KS = O::KS;
 
     extern __shared__ double sOps[];
-    stage_image<O::DOUBLES, 256>(sOps, p.opsAffine);
+    stage_image<O::DOUBLES, THREADS>(sOps, p.opsAffine);
     __syncthreads();
 
     const unsigned lane = threadIdx.x & 63u, q = lane >> 4, j = lane & 15u;
     // XCD-aware, contiguous chunks of tiles per wave (neighbouring tiles share an L2)
     const unsigned nwg = gridDim.x, xcd = blockIdx.x % 8u, q8 = nwg / 8u, r8 = nwg % 8u;
     const unsigned blk = (xcd < r8 ? xcd * (q8 + 1u) : r8 * (q8 + 1u) + (xcd - r8) * q8) + blockIdx.x / 8u;
-    const unsigned wave = blk * 4u + (threadIdx.x >> 6), nwaves = nwg * 4u;
+    const unsigned wave = blk * WAVES + (threadIdx.x >> 6), nwaves = nwg * WAVES;
     const unsigned ntiles = (static_cast<unsigned>(p.kend - p.kbegin) + 15u) / 16u;
     const unsigned perWave = (ntiles + nwaves - 1u) / nwaves;
     const unsigned tileEnd = min(ntiles, (wave + 1u) * perWave);

@@ -267,6 +267,13 @@ hipError_t stageMfmaHalo(const StageParams& p, hipStream_t stream) {
         hipLaunchKernelGGL((sw2d_stage_mfma_kernel<kN, MODE_LSERK, true, true>), dim3(grid), dim3(256), ldsBytes, stream, p);
         return hipGetLastError();
     }
+    // event form (2- and 4-way splits of N <= 4: the interior share runs on the unrolled kernel): one-wave workgroups, one tile each, so that
+    // the launch finds room beside the interior launch (sw2d_stage_mfma_kernel, THREADS); BDG_SW2D_STRIP_WORKGROUP=256 restores the four-wave form
+    static const bool fourWaves = [] { const char* e = std::getenv("BDG_SW2D_STRIP_WORKGROUP"); return e && std::atoi(e) == 256; }();
+    if (!fourWaves && kN <= 4) {
+        BDG_LAUNCH_EV((sw2d_stage_mfma_kernel<kN, MODE_LSERK, true, false, 64>), dim3(std::min(ntiles, 2048u * perCu)), dim3(64), ldsBytes, stream, p);
+        return hipGetLastError();
+    }
     BDG_LAUNCH_EV((sw2d_stage_mfma_kernel<kN, MODE_LSERK, true>), dim3(grid), dim3(256), ldsBytes, stream, p);
     return hipGetLastError();
 }
