@@ -661,15 +661,19 @@ struct bdg_sw2d {
         return numInterior > 0 && affineVariant == 0 && numInterior < (smallPinned >= 0 ? smallPinned : kSmallLaunch[N]);
     }
     // a bounded in-kernel wait that gave up (sync_wait) left a mark: report it the next time the host looks at the device
-    void checkSyncError() {
-        if (!syncBuf.p) return;
+    bool takeSyncMark() { // true (and the mark cleared) if a wait of this device gave up since the last look
+        if (!syncBuf.p) return false;
         unsigned long long mark = 0;
         hipCheck(hipMemcpy(&mark, syncBuf.p + 2, sizeof(mark), hipMemcpyDeviceToHost), "sync word download");
-        if (mark != 0) {
-            hipCheck(hipMemset(syncBuf.p + 2, 0, sizeof(mark)), "hipMemset");
-            throw std::runtime_error("an in-kernel wait between the interior and the partition-boundary launch of an exchanged stage "
-                                     "timed out: the results of this run are not valid (BDG_SW2D_EVENT_SYNC=1 restores event waits)");
-        }
+        if (mark != 0) hipCheck(hipMemset(syncBuf.p + 2, 0, sizeof(mark)), "hipMemset");
+        return mark != 0;
+    }
+    static const char* syncErrorText() {
+        return "an in-kernel wait between the interior and the partition-boundary launch of an exchanged stage "
+               "timed out: the results of this run are not valid (BDG_SW2D_EVENT_SYNC=1 restores event waits)";
+    }
+    void checkSyncError() {
+        if (takeSyncMark()) throw std::runtime_error(syncErrorText());
     }
     // LSERK4 stage of the partition-boundary elements: reads ghost traces from recv, writes send records
     // ringExpected (flagSync): the ring-tile count the interior launch of the PREVIOUS stage brings the counter to
@@ -1954,10 +1958,28 @@ int bdg_sw2d_comm_init(bdg_sw2d* s, int rank, int world, const void* unique_id, 
         const size_t rows = static_cast<size_t>(s->nf) * s->Np;
         s->sendBuf.alloc(std::max<size_t>(1, static_cast<size_t>(s->numSend) * rows), s->bytes);
         s->recvBuf.alloc(std::max<size_t>(1, static_cast<size_t>(ghosts) * rows), s->bytes);
+        hipCheck(hipMemset(s->sendBuf.p, 0, s->sendBuf.n * sizeof(double)), "hipMemset");
+        hipCheck(hipMemset(s->recvBuf.p, 0, s->recvBuf.n * sizeof(double)), "hipMemset");
         s->scalarBuf.alloc(2, s->bytes);
         s->syncBuf.alloc(8, s->bytes);
         hipCheck(hipMemset(s->syncBuf.p, 0, 8 * sizeof(unsigned long long)), "hipMemset");
         s->expectRing = s->expectStrip = 0;
+        // The first send / receive between two ranks sets their connection up (host side, inside ncclGroupEnd, and only as fast as the
+        // slower of the two gets there). Do that HERE, where every rank is anyway and nothing is in flight: one double each way with
+        // every neighbour, in the buffers and with the pairing of the stage exchange. Otherwise it would happen in the first exchanged
+        // stage, behind interior launches whose ring tiles wait -- with a bound -- for the launches queued behind that exchange.
+        if (!s->peers.empty() && !std::getenv("BDG_SW2D_NO_COMM_WARMUP")) {
+            RcclApi& nc = rccl();
+            ncclCheck(nc.GroupStart(), "ncclGroupStart");
+            for (const bdg_sw2d::Peer& pr : s->peers) {
+                if (pr.recvCount > 0)
+                    ncclCheck(nc.Recv(s->recvBuf.p + static_cast<size_t>(pr.recvStart) * rows, 1, ncclDouble, pr.rank, s->comm, s->commStream), "ncclRecv");
+                if (pr.sendCount > 0)
+                    ncclCheck(nc.Send(s->sendBuf.p + static_cast<size_t>(pr.sendStart) * rows, 1, ncclDouble, pr.rank, s->comm, s->commStream), "ncclSend");
+            }
+            ncclCheck(nc.GroupEnd(), "ncclGroupEnd");
+            hipCheck(hipStreamSynchronize(s->commStream), "hipStreamSynchronize");
+        }
     });
 }
 
@@ -2147,9 +2169,13 @@ int bdg_sw2d_barrier(bdg_sw2d* s) {
         s->use();
         hipCheck(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
         if (s->commStream) hipCheck(hipStreamSynchronize(s->commStream), "hipStreamSynchronize");
-        s->checkSyncError();
-        (void)s->allReduceScalar(0.0, true); // every rank arrives before anyone leaves
+        // every rank arrives before anyone leaves -- and a wait that gave up on ANY rank is reported by ALL of them here (a rank that
+        // threw before the reduction would leave the others inside it), so that the callers can react together
+        const bool mine = s->takeSyncMark();
+        const double any = s->allReduceScalar(mine ? 1.0 : 0.0, true);
         hipCheck(hipDeviceSynchronize(), "hipDeviceSynchronize");
+        if (mine) throw std::runtime_error(bdg_sw2d::syncErrorText());
+        if (any != 0.0) throw std::runtime_error(std::string("on another rank: ") + bdg_sw2d::syncErrorText());
     });
 }
 
