@@ -355,7 +355,7 @@ struct bdg_sw2d {
                     ph.slope = 1.0; ph.dragSign = -1.0;
                     ph.H = vb.H; ph.obc = vb.obc; ph.lam = lamBuf.p; ph.spongeField = vb.sponge; ph.tide = vb.tide;
                     p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
-                    hipCheck(kt->stageMfma2Src(mode, p, ph, variantBStateOnce() ? 6 : 2, st), what);
+                    hipCheck(kt->stageMfma2Src(mode, p, ph, variantBStateOnce() ? (6 | srcIdentity(filter)) : 2, st), what);
                 } else {
                     p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
                     hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 6, nullptr, st), what);
@@ -389,7 +389,7 @@ struct bdg_sw2d {
                 ph.slope = 1.0; ph.dragSign = -1.0;             // src/sw2d/main.cpp:461-478
                 ph.H = vb.H; ph.obc = vb.obc; ph.lam = lamBuf.p; ph.spongeField = vb.sponge; ph.tide = vb.tide;
                 p.opsAffine = filter ? opsMfma2SrcFiltered.p : opsMfma2Src.p;
-                hipCheck(kt->stageMfma2Src(mode, p, ph, variantBStateOnce() ? 6 : 2, st), what);
+                hipCheck(kt->stageMfma2Src(mode, p, ph, variantBStateOnce() ? (6 | srcIdentity(filter)) : 2, st), what);
             } else {
                 p.opsAffine = filter ? opsVdFiltered.p : opsVd.p;
                 hipCheck(kt->stageVb(mode, p, vb, vbPartials.p, lamBuf.p, 0, nullptr, st), what);
@@ -429,14 +429,14 @@ struct bdg_sw2d {
             const bool stateOnceSrc = !std::getenv("BDG_SW2D_SOURCES_TWO_WAVE");
             if (stateOnceSrc && kt->mfma3SrcFields >= nf && !std::getenv("BDG_SW2D_TRACER_PASS") &&
                 static_cast<long long>(nf) * Np * ld * 8 <= 4294967295LL) {
-                hipCheck(kt->stageMfma2Src(mode, p, ph, nf == 4 ? 5 : 4, st), what);
+                hipCheck(kt->stageMfma2Src(mode, p, ph, (nf == 4 ? 5 : 4) | srcIdentity(filter), st), what);
             } else if (stateOnceSrc && kt->mfma3TracerPhase && nf == 4 && !std::getenv("BDG_SW2D_TRACER_PASS") &&
                        static_cast<long long>(4) * Np * ld * 8 <= 4294967295LL) {
                 // N = 8: the tracer equation as a second phase of every tile, from the state tile still in LDS (one launch, state read once)
-                hipCheck(kt->stageMfma2Src(mode, p, ph, 7, st), what);
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 7 | srcIdentity(filter), st), what);
             } else if (stateOnceSrc && kt->mfma3SrcFields == 3 && nf == 4 && static_cast<long long>(3) * Np * ld * 8 <= 4294967295LL) {
                 // N = 8: three conserved fields with sources on the state-once schedule, the tracer in its own pass
-                hipCheck(kt->stageMfma2Src(mode, p, ph, 4, st), what);
+                hipCheck(kt->stageMfma2Src(mode, p, ph, 4 | srcIdentity(filter), st), what);
                 p.opsAffine = filter ? opsMfma2Filtered.p : opsMfma2.p;
                 hipCheck(kt->stageMfma2Src(mode, p, ph, 1, st), what);
             } else if (nf == 4 && kt->mfmaMT <= 2 && !std::getenv("BDG_SW2D_TRACER_PASS")) {
@@ -661,6 +661,12 @@ struct bdg_sw2d {
         return numInterior > 0 && affineVariant == 0 && numInterior < (smallPinned >= 0 ? smallPinned : kSmallLaunch[N]);
     }
     // a bounded in-kernel wait that gave up (sync_wait) left a mark: report it the next time the host looks at the device
+    // unfiltered evaluation on a state-once kernel with sources: F' is the identity, the sources are added pointwise (IDF instance;
+    // BDG_SW2D_SOURCES_PRODUCT=1 keeps the products with the identity tiles for A/B runs and cross-checks -- bit-identical)
+    static int srcIdentity(bool filter) {
+        const char* product = std::getenv("BDG_SW2D_SOURCES_PRODUCT"); // (read per call: the cross-check switches it within one process)
+        return (!filter && !(product && product[0] != '0')) ? bdg_dev::kSrcIdentity : 0;
+    }
     bool takeSyncMark() { // true (and the mark cleared) if a wait of this device gave up since the last look
         if (!syncBuf.p) return false;
         unsigned long long mark = 0;

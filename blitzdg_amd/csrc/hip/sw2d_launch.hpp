@@ -16,6 +16,8 @@
 
 namespace bdg_dev {
 
+constexpr int kSrcIdentity = 16; // stageMfma2Src's tracer argument, state-once forms: "the image's F' tiles are the identity" (no filter)
+
 struct KernelTable {
     int order, Np, Nfp, ldsDoubles;
     // mode: StageMode; launches one fused RHS(+stage update) pass over K elements.

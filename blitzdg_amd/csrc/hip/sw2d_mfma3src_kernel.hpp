@@ -42,7 +42,13 @@ struct Mfma3SrcLds {
 // element) take the tide elevation, hydrostatic-reconstruction star states, the GLOBAL Lax-Friedrichs speed (a device
 // scalar reduced beforehand), sources with the depth gradient (slope = +1, dragSign = -1), and in combine steps the
 // per-node sponge coefficient. No tracer.
-template <int N, int MODE, bool TRACER, int PHYS = 1, bool TPHASE = false>
+// IDF (round 4): the evaluation is not filtered, F' is the identity -- the sources are ADDED to the accumulator element of their own
+// node (the lane that forms S(node 4 t + q) holds accumulator row 4 t + q of block t >> 2 as element t & 3) instead of being multiplied
+// by MT KV identity tiles: 2 MT KV fewer matrix instructions per tile (72 of 369 at N = 8, three fields). The add goes where the
+// product went in the order of operations on that accumulator (after the k-step's D products, i.e. in front of the next k-step's
+// matrix instructions, behind that step's pointwise work: the products it follows have long retired), and the other row blocks'
+// F' tiles are zero: bit-identical to the product form.
+template <int N, int MODE, bool TRACER, int PHYS = 1, bool TPHASE = false, bool IDF = false>
 __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const StageParams p, const PhysParams ph) {
     static_assert(PHYS == 1 || (PHYS == 2 && !TRACER), "variant B has three fields");
     static_assert(!TPHASE || (PHYS == 1 && !TRACER), "the tracer phase follows the three-field form of variants C / D");
@@ -61,7 +67,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
     constexpr bool PF2 = TPHASE && !PF;
 
     extern __shared__ double sOps[];
-    stage_image<IMAGE, 256>(sOps, p.opsAffine);
+    stage_image<IDF ? O::DOUBLES : IMAGE, 256>(sOps, p.opsAffine); // (IDF: the F' tiles are not used; the tiles' places in LDS stay where they are)
     __syncthreads();
     const int sBase = IMAGE + static_cast<int>(threadIdx.x >> 6) * L::TILE_DOUBLES + static_cast<int>(threadIdx.x & 15u);
 
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
         if constexpr (PF && PHYS == 2) btagsN = bld_i32(robc, kN * 4u, 0u);
         __builtin_amdgcn_sched_barrier(0);
         constexpr int OLD_EARLY = (MT > 1 ? 4 * (MT - 1) : 0) < KV ? (MT > 1 ? 4 * (MT - 1) : 0) : KV;
+        double ssPend[2] = {0.0, 0.0}; // (IDF) the previous k-step's sources, added in front of this step's matrix instructions
 #pragma unroll
         for (int t = 0; t < KV; ++t) {
             double ab[2 * NF], ss[2];
@@ -331,19 +338,33 @@ __global__ __launch_bounds__(256, 1) void sw2d_stage_mfma3src_kernel(const Stage
 #pragma unroll
             for (int it = t * PER_STEP; it < (t + 1) * PER_STEP; ++it)
                 if (it < FACE_ITEMS) faceNode(it / KF, it % KF);
+            if constexpr (IDF) {
+                if (t > 0) {
+                    acc[1][(t - 1) >> 2][(t - 1) & 3] += ssPend[0];
+                    acc[2][(t - 1) >> 2][(t - 1) & 3] += ssPend[1];
+                }
+                ssPend[0] = ss[0];
+                ssPend[1] = ss[1];
+            }
 #pragma unroll
             for (int r2 = 0; r2 < MT; ++r2) {
                 const double Adr = sOps[O::OFF_DR + (r2 * KV + t) * 64 + lane];
                 const double Ads = sOps[O::OFF_DS + (r2 * KV + t) * 64 + lane];
-                const double Af = sOps[OFF_F + (r2 * KV + t) * 64 + lane];
 #pragma unroll
                 for (int c = 0; c < NF; ++c) acc[c][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Adr, ab[2 * c], acc[c][r2], 0, 0, 0);
 #pragma unroll
                 for (int c = 0; c < NF; ++c) acc[c][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Ads, ab[2 * c + 1], acc[c][r2], 0, 0, 0);
-                acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af, ss[0], acc[1][r2], 0, 0, 0);
-                acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af, ss[1], acc[2][r2], 0, 0, 0);
+                if constexpr (!IDF) {
+                    const double Af = sOps[OFF_F + (r2 * KV + t) * 64 + lane];
+                    acc[1][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af, ss[0], acc[1][r2], 0, 0, 0);
+                    acc[2][r2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Af, ss[1], acc[2][r2], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (IDF) {
+            acc[1][(KV - 1) >> 2][(KV - 1) & 3] += ssPend[0];
+            acc[2][(KV - 1) >> 2][(KV - 1) & 3] += ssPend[1];
         }
 #pragma unroll
         for (int t = OLD_EARLY; t < KV; ++t) loadOldRow(t);

@@ -420,10 +420,14 @@ hipError_t stageMfma3(int mode, const StageParams& p, hipStream_t stream) {
 // matrix-core kernel with the momentum sources (operator image: MfmaOps2 + MT*KV tiles of F'); tracer = 1
 // launches the tracer pass instead (plain MfmaOps2 image), tracer = 2 the variant-B form (same image as the
 // sources), tracer = 3 sources and tracer fused (N <= 6). Orders above the unrolled kernels' range only.
+// tracer | kSrcIdentity (state-once forms 4 ... 7): the caller's image holds identity F' tiles (no filter) -- the instance that adds
+// the sources pointwise instead of multiplying by them (IDF, sw2d_mfma3src_kernel.hpp)
 template <int MODE>
-hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer, hipStream_t stream) {
+hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracerArg, hipStream_t stream) {
     if constexpr (!kMfmaSources) return hipErrorNotSupported;
     else {
+    const int tracer = tracerArg & ~kSrcIdentity;
+    const bool idf = (tracerArg & kSrcIdentity) != 0 && tracer >= 4 && tracer <= 7;
     if (p.kend <= p.kbegin) return hipSuccess;
     using O = MfmaOps2<kN>;
     const size_t ldsBytes = sizeof(double) * (O::DOUBLES + (tracer == 1 ? 0 : O::MT * O::KV * 64));
@@ -450,16 +454,21 @@ hipError_t launchMfma2Src(const StageParams& p, const PhysParams& ph, int tracer
             };
             if (tracer == 5) {
                 if constexpr (kMfma3SrcFields >= 4)
-                    return launch(sw2d_stage_mfma3src_kernel<kN, MODE, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
+                    return idf ? launch(sw2d_stage_mfma3src_kernel<kN, MODE, true, 1, false, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES)
+                               : launch(sw2d_stage_mfma3src_kernel<kN, MODE, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
                 else return hipErrorNotSupported;
             }
             if (tracer == 7) {
                 if constexpr (kTracerPhase)
-                    return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 1, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
+                    return idf ? launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 1, true, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES)
+                               : launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 1, true>, sizeof(double) * Mfma3SrcLds<kN, true>::DOUBLES);
                 else return hipErrorNotSupported;
             }
-            if (tracer == 6) return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 2>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
-            return launch(sw2d_stage_mfma3src_kernel<kN, MODE, false>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
+            if (tracer == 6)
+                return idf ? launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 2, false, true>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES)
+                           : launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 2>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
+            return idf ? launch(sw2d_stage_mfma3src_kernel<kN, MODE, false, 1, false, true>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES)
+                       : launch(sw2d_stage_mfma3src_kernel<kN, MODE, false>, sizeof(double) * Mfma3SrcLds<kN, false>::DOUBLES);
         }
     }
     if (tracer == 3) { // sources + tracer in one pass (MT <= 2)

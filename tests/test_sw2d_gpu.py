@@ -1195,6 +1195,55 @@ def test_variant_b_on_the_state_once_kernel_on_many_tiles(order, nx, ny, monkeyp
     assert relmax(out[False][2][1], e["hu"]) > 1e-7               # the state moved
 
 
+@pytest.mark.parametrize("order,nx,ny,fields", [(5, 23, 19, 4), (6, 21, 19, 3), (7, 19, 17, 4), (8, 17, 23, 3), (8, 19, 15, 4)])
+def test_unfiltered_sources_added_pointwise_equal_the_identity_products(order, nx, ny, fields, monkeypatch):
+    """Unfiltered evaluations on the state-once kernels with sources add the sources to the accumulator element of their node
+    (IDF instances, round 4) where the filtered ones multiply them by the tiles of F'. BDG_SW2D_SOURCES_PRODUCT=1 keeps the products --
+    by identity tiles then: same operations on every accumulator in the same order, so RHS, LSERK4 stages and SSP-RK2 + sponge
+    steps of variants C / D and B are the same bit for bit."""
+    from conftest import variant_b_setup
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(nx, ny, shuffleSeed=5)
+    nodes = dg.TriangleNodesProvisioner(order, mesh)
+    t = tables_from_nodes(nodes)
+    x, y = t["x"], t["y"]
+    h, hu, hv = seeded_fields(x, y, seed=order + 40)
+    hN = h * (0.3 + 0.2 * np.sin(2 * x + y))
+    src = {"zx": 0.02 * np.cos(x) + 0.01, "zy": 0.015 * np.sin(2 * y), "f": 0.07 + 0.01 * y, "CD": 2.5e-3}
+    out = {}
+    for product in (True, False):
+        if product:
+            monkeypatch.setenv("BDG_SW2D_SOURCES_PRODUCT", "1")
+        else:
+            monkeypatch.delenv("BDG_SW2D_SOURCES_PRODUCT")
+        s = sw2d.Sw2dSolver(tables=t, g=9.81, flags=sw2d.KEEP_ORDER, fields=fields, sources=src)
+        q = (h, hu, hv, hN)[:fields]
+        set_state, get_state = (s.setState4, s.getState4) if fields == 4 else (s.setState, s.getState)
+        res = list((s.computeRHS4 if fields == 4 else s.computeRHS)(*q))
+        set_state(*q)
+        dt, _ = s.computeDt(0.4)
+        s.lserk4Stages(dt, 6)
+        res += list(get_state())
+        set_state(*q)
+        s.stepSSPRK2(dt, 2, False, 1e-3)
+        res += list(get_state())
+        s.close()
+        if fields == 3:                                            # variant B on the same mesh
+            nodesB, tB, e = variant_b_setup(order, mesh)
+            Hx, Hy = nodesB.bedSlopes(e["H"])
+            b = _variant_b_solver(nodesB, e, Hx, Hy, sponge=2e-3 * np.exp(-4 * (tB["x"] + 1.0) ** 2))
+            res += list(b.computeRHS(e["h"], e["hu"], e["hv"]))
+            b.setState(e["h"], e["hu"], e["hv"])
+            b.lserk4Stages(0.1 * b.computeDt(0.5)[0], 5)
+            res += list(b.getState())
+            b.close()
+        out[product] = res
+    assert len(out[True]) == len(out[False]) >= 3 * fields
+    for u, v in zip(out[True], out[False]):
+        assert np.array_equal(u, v)
+    assert relmax(out[False][fields + 1], hu) > 1e-6               # the state moved
+
+
 @pytest.mark.parametrize("case", ["coarse_box_N4", "coarse_box_N6"])
 def test_tracer_in_its_own_pass_as_cross_check(case, monkeypatch):
     """By default the tracer equation rides in the three-field kernel as a fourth accumulator set (N <= 6);
