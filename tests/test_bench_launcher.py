@@ -97,3 +97,62 @@ def test_file_rendezvous_ignores_a_record_older_than_the_launcher(tmp_path, monk
     t.join()
     assert uid == fresh and path == str(stale)
     assert (os.stat(path).st_mode & 0o777) == 0o600
+
+
+def test_a_timed_out_in_kernel_wait_makes_every_rank_measure_again_with_event_waits(monkeypatch, capsys):
+    """bench.py --gpus N, one rank's view: the barrier after the warm-up reports that an in-kernel wait between the two launches of a
+    stage gave up somewhere (the library reports it from every rank's barrier) -- the measurement starts over from the initial state
+    with BDG_SW2D_EVENT_SYNC=1 and the line says which form of the dependencies was measured. Any other error is not retried."""
+    import bench
+    import blitzdg_amd.halo as halo
+    import blitzdg_amd._capi as capi
+
+    class Stub:
+        global_elements, Np = 1000, 15
+
+        def __init__(self, fail_with):
+            self.fail_with, self.calls, self.uploads = fail_with, [], 0
+
+        def set_initial_state(self, fn): self.uploads += 1
+        def compute_dt(self, cfl): return 1e-3
+        def lserk4_stages(self, dt, n): self.calls.append((n, os.environ.get("BDG_SW2D_EVENT_SYNC")))
+
+        def barrier(self):
+            if self.fail_with and len(self.calls) == 1:
+                raise RuntimeError(self.fail_with)
+
+        def allreduce_max(self, v): return max(v, 1e-3)
+        def allreduce_sum(self, v): return v
+        def owned_mass(self, fn=None): return 1.0
+        def halo_counts(self): return {"owned": 500}
+        def close(self): pass
+
+    class Lib:
+        @staticmethod
+        def bdg_device_count(): return 1
+
+    monkeypatch.setattr(capi, "lib", Lib, raising=False)
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.delenv("BDG_SW2D_EVENT_SYNC", raising=False)
+    args = argparse.Namespace(steps=7, warmup=3, gpus=2)
+    stub = Stub("on another rank: an in-kernel wait between the interior and the partition-boundary launch of an exchanged stage timed out")
+    monkeypatch.setattr(halo.NativeDistributedSw2d, "box", classmethod(lambda cls, *a, **k: stub))
+    bench.run_distributed_native(args)
+    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1])
+    assert stub.uploads == 2 and stub.calls == [(3, None), (3, "1"), (7, "1")]
+    assert line["n_gpus"] == 2 and line["config"]["stage_dependencies"].startswith("events (an in-kernel wait timed out")
+    monkeypatch.delenv("BDG_SW2D_EVENT_SYNC", raising=False)
+    os.environ.pop("BDG_SW2D_EVENT_SYNC", None)
+
+    clean = Stub(None)
+    monkeypatch.setattr(halo.NativeDistributedSw2d, "box", classmethod(lambda cls, *a, **k: clean))
+    bench.run_distributed_native(args)
+    line = json.loads([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1])
+    assert clean.uploads == 1 and clean.calls == [(3, None), (7, None)] and line["config"]["stage_dependencies"].startswith("in-kernel")
+
+    broken = Stub("hipErrorLaunchFailure")
+    monkeypatch.setattr(halo.NativeDistributedSw2d, "box", classmethod(lambda cls, *a, **k: broken))
+    with pytest.raises(RuntimeError, match="hipErrorLaunchFailure"):
+        bench.run_distributed_native(args)
+    assert broken.uploads == 1
