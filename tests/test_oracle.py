@@ -292,6 +292,26 @@ def test_variant_b_global_speed_star_states_and_tide(coarse_mesh):
     assert max(np.abs(x).max() for x in rest) < 1e-10
 
 
+def test_variant_b_still_water_over_a_bed_that_jumps_between_elements_stays_still(coarse_mesh):
+    """A property of the reference's scheme that needs no vector (src/sw2d/main.cpp:357-368): with the hydrostatic star states
+    h* = max(0, h - H + min(H-, H+)) both sides of a face see the same depth when the surface is level, so still water over a bed that
+    is constant per element and jumps at every face has a vanishing right-hand side -- and a bump in one element does not."""
+    from conftest import variant_b_setup
+    from oracle import oracle_np as onp
+    nodes, t, e = variant_b_setup(4, coarse_mesh)
+    K = t["x"].shape[1]
+    H = np.tile(9.0 + 3.0 * np.random.default_rng(4).random(K), (t["x"].shape[0], 1))
+    zero = 0 * H
+    moving = onp.sw2d_rhs_b(e["h"], e["hu"], e["hv"], e["H"], *onp.bed_slopes(e["H"], t), 9.81, e["f"], e["CD"], 0.0, t, ())
+    scale = max(np.abs(x).max() for x in moving)
+    rest = onp.sw2d_rhs_b(H + 0.25, zero, zero, H, zero, zero, 9.81, e["f"], e["CD"], 0.0, t, ())
+    assert max(np.abs(x).max() for x in rest) < 1e-13 * scale
+    h = H + 0.25
+    h[:, K // 2] += 0.01
+    bump = onp.sw2d_rhs_b(h, zero, zero, H, zero, zero, 9.81, e["f"], e["CD"], 0.0, t, ())
+    assert max(np.abs(x).max() for x in bump) > 1e-6 * scale
+
+
 def test_variant_b_host_helpers_match_the_restatement(coarse_mesh):
     from conftest import variant_b_setup
     from oracle import oracle_np as onp

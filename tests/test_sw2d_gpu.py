@@ -529,6 +529,36 @@ def test_variant_b_rhs_vs_oracle(order, coarse_mesh):
     del col
 
 
+@pytest.mark.parametrize("order", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_variant_b_still_water_over_a_bed_that_jumps_between_elements_stays_still(order, coarse_mesh):
+    """The hydrostatic star states of the reference's tidal driver (src/sw2d/main.cpp:357-368) without any vector: still water over
+    a bed that is constant per element and jumps at every face -- both sides of a face then reconstruct the same depth -- has a
+    vanishing right-hand side on every kernel family (unrolled, state-once, per-node tables), and a bump in one element does not."""
+    from conftest import variant_b_setup
+    nodes, t, e = variant_b_setup(order, coarse_mesh)
+    K = t["x"].shape[1]
+    H = np.tile(9.0 + 3.0 * np.random.default_rng(4).random(K), (t["x"].shape[0], 1))
+    zero = 0 * H
+    moving = _variant_b_solver(nodes, e, *nodes.bedSlopes(e["H"])).computeRHS(e["h"], e["hu"], e["hv"])
+    scale = max(np.abs(x).max() for x in moving)
+    for flags in (0, sw2d.NODAL_GEOMETRY):
+        s = sw2d.Sw2dSolver(nodes=nodes, flags=flags)
+        s.enableVariantB(H, zero, zero, CD=e["CD"], f=e["f"])              # closed basin: no tide enters
+        rest = s.computeRHS(H + 0.25, zero, zero)
+        assert max(np.abs(x).max() for x in rest) < 1e-13 * scale
+        assert max(np.abs(x).max() for x in s.computeRHS(H + 0.25, zero, zero, filter=True)) < 1e-13 * scale
+        h = H + 0.25
+        h[:, K // 2] += 0.01
+        assert max(np.abs(x).max() for x in s.computeRHS(h, zero, zero)) > 1e-6 * scale
+        s.setState(H + 0.25, zero, zero)                                    # and it stays still through the time stepping
+        dt = 0.2 * s.computeDt(0.5)[0]
+        s.lserk4Stages(dt, 10)
+        s.stepSSPRK2(dt, 2, False, 1e-3)
+        hh, hu, hv = s.getState()
+        assert np.abs(hh - (H + 0.25)).max() < 1e-12 and max(np.abs(hu).max(), np.abs(hv).max()) < 1e-12
+        s.close()
+
+
 @pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N6"])
 def test_variant_b_matches_the_reference_function_where_it_degenerates_to_it(case):
     """The HIP variant-B path (global Lax-Friedrichs speed, star states, Coriolis source) against the output of the
