@@ -557,6 +557,20 @@ def test_variant_b_still_water_over_a_bed_that_jumps_between_elements_stays_stil
         hh, hu, hv = s.getState()
         assert np.abs(hh - (H + 0.25)).max() < 1e-12 and max(np.abs(hu).max(), np.abs(hv).max()) < 1e-12
         s.close()
+        # the open boundary (:348-353) sets the outer depth to H + tide(t): a basin whose level IS the tide elevation of that moment is
+        # at rest there too, one at another level is not -- and only in the elements on that boundary
+        from oracle import oracle_np as onp
+        tb = sw2d.Sw2dSolver(nodes=nodes, flags=flags)
+        tb.enableVariantB(H, zero, zero, mapO=e["mapO"], CD=e["CD"], f=e["f"])
+        tb.time = e["time"]
+        eta = onp.tide_elevation(e["time"])
+        assert abs(eta) > 0.1
+        assert max(np.abs(x).max() for x in tb.computeRHS(H + eta, zero, zero)) < 1e-13 * scale
+        off = tb.computeRHS(H + eta + 0.05, zero, zero)
+        touched = np.unique(np.nonzero(np.abs(off[0]) > 1e-9 * scale)[1])
+        on_boundary = np.unique(t["vmapM"].reshape(-1)[e["mapO"]] // t["x"].shape[0])
+        assert len(touched) > 0 and set(touched) <= set(on_boundary)
+        tb.close()
 
 
 @pytest.mark.parametrize("case", ["coarse_box_N3", "box6x5_shuffled_N6"])
