@@ -263,3 +263,39 @@ def test_plan_is_consistent_between_ranks():
             assert np.array_equal(q.halo_global[match[0][0]:match[0][0] + count], sent)
         # local mesh is orientation-preserving and compact
         assert p.local_EToV.max() == p.local_verts.shape[0] - 1
+
+
+@pytest.mark.parametrize("world,mesh_args", [(2, (9, 7, 0)), (3, (11, 8, 5)), (4, (12, 10, 0)), (8, (24, 12, 7))])
+def test_plan_orders_owned_elements_deep_ring_boundary(world, mesh_args):
+    """The invariants the partitioned stage builds on (halo.build_plan), for every rank of a split: the owned
+    elements come as [deep interior | ring | partition boundary]; a boundary element has a ghost neighbour, an interior one has none
+    (bdg_sw2d_set_partition refuses otherwise); ring elements are exactly the interior ones next to a boundary element, so a deep
+    element touches neither a ghost nor a boundary element; the send list holds boundary elements only, and every rank's receive
+    ranges are its neighbours' send ranges in the same order."""
+    sys.path.insert(0, ROOT)
+    import blitzdg_amd.pyblitzdg as dg
+    from blitzdg_amd.halo import build_plan
+    mesh = dg.MeshManager()
+    mesh.buildBoxMesh(*mesh_args[:2], shuffleSeed=mesh_args[2])
+    mesh.partitionMesh(world)
+    EToE = np.asarray(mesh.EToE).reshape(-1, 3)
+    epart = np.asarray(mesh.elementPartitionMap).reshape(-1)
+    plans = [build_plan(mesh.elements, mesh.vertices, mesh.EToE, epart, r, world, bctype=mesh.bcType) for r in range(world)]
+    assert sorted(np.concatenate([p.own_global for p in plans]).tolist()) == list(range(EToE.shape[0]))
+    for p in plans:
+        own = p.own_global
+        assert (epart[own] == p.rank).all()
+        remote = epart[EToE[own]] != p.rank                                  # (K_own, 3)
+        is_boundary = remote.any(axis=1)
+        assert not is_boundary[:p.num_interior].any() and is_boundary[p.num_interior:].all()
+        boundary_ids = set(own[p.num_interior:].tolist())
+        touches = np.array([[int(n) in boundary_ids for n in row] for row in EToE[own[:p.num_interior]]]).reshape(-1, 3).any(axis=1)
+        first_ring = int(np.argmax(touches)) if touches.any() else p.num_interior
+        assert not touches[:first_ring].any() and touches[first_ring:].all()    # [deep | ring]: one switch, no mixing
+        assert set(p.send_local.tolist()) <= set(range(p.num_interior, p.num_owned))
+        assert set(p.halo_global.tolist()) == set(EToE[own][remote].tolist())
+        for peer, start, count in p.recv_slices:
+            back = [(s, c) for (q, s, c) in plans[peer].send_slices if q == p.rank]
+            assert len(back) == 1 and back[0][1] == count
+            sent = plans[peer].own_global[plans[peer].send_local[back[0][0]:back[0][0] + count]]
+            assert np.array_equal(sent, p.halo_global[start:start + count])
