@@ -192,8 +192,10 @@ def also_block():
     out = {}
     ms, K, Np, _, affine = also_measure(8, (500, 250))
     gbps = algorithmic_bytes_per_element(8) * K / (ms * 1e-3) / 1e9
+    traffic, source = committed_traffic(8, K)   # PMC passes of `bench.py --order 8 --cells 500x250` at these sources, or None
     out["config5_n8"] = {"ms": ms, "elements": K, "order": 8, "updates_per_s": Np * K / (ms * 1e-3), "achieved_GBps": gbps,
-                         "frac": gbps / HBM_PEAK_GBPS, "kernel": stage_kernel_name(8, K, affine), "stages_timed": ALSO_STAGES, "ramp_stages_untimed": ALSO_RAMP}
+                         "frac": gbps / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
+                         "kernel": stage_kernel_name(8, K, affine), "stages_timed": ALSO_STAGES, "ramp_stages_untimed": ALSO_RAMP}
     ms_given, K, Np, renum_given, _ = also_measure(4, (1000, 500), shuffle_seed=12345, keep_order=True)
     ms_renum, _, _, renum, affine = also_measure(4, (1000, 500), shuffle_seed=12345)
     gbps = algorithmic_bytes_per_element(4) * K / (ms_renum * 1e-3) / 1e9
